@@ -1,0 +1,457 @@
+// C-ABI host side of liblbm_hip.so (declarations and reference citations: include/lbm_hip.h).
+// No torch types, no exceptions across the boundary, no CPU fallback.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/lbm_hip.h"
+#include "lbm_internal.h"
+
+using namespace lbm;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? LBM_ERR_NOMEM : LBM_ERR_HIP,            \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct lbm_solver {
+    lbm_config cfg;
+    Geom geo;
+    int xmode;
+    bool half;
+    int T;
+    hipStream_t own_stream, stream;
+    void* buf[2];
+    size_t buf_bytes;
+    int cur;
+    uint64_t* mask;
+    size_t mask_bytes;
+    bool pulled;       // buf[cur] holds g = collide(f_{steps-1}); false: holds f_steps itself
+    int64_t steps;
+    int ghost_valid;   // valid ghost rows beyond each seam
+    void* staging;     // device staging for host-layout windows
+    size_t staging_bytes;
+    uint8_t* frame_dev;
+    hipEvent_t ev0, ev1;
+};
+
+static const size_t STAGING_BYTES = 256ull << 20;
+
+static int check(lbm_solver* s) {
+    if (!s) return fail(LBM_ERR_INVALID, "null solver handle");
+    HIPCHK(hipSetDevice(s->cfg.device));
+    return LBM_OK;
+}
+#define ENTER(s)                      \
+    do {                              \
+        int rc_ = check(s);           \
+        if (rc_ != LBM_OK) return rc_; \
+    } while (0)
+
+static size_t elem_size(const lbm_solver* s) { return s->half ? 2 : 4; }
+static bool seam_top(const lbm_solver* s) { return s->geo.top == YEDGE_GHOST; }
+static bool seam_bot(const lbm_solver* s) { return s->geo.bot == YEDGE_GHOST; }
+
+extern "C" {
+
+int lbm_abi_version(void) { return LBM_ABI_VERSION; }
+const char* lbm_last_error(void) { return g_err; }
+
+int lbm_device_count(int* count) {
+    if (!count) return fail(LBM_ERR_INVALID, "count is null");
+    *count = 0;
+    HIPCHK(hipGetDeviceCount(count));
+    return LBM_OK;
+}
+
+int lbm_create(const lbm_config* cfg, lbm_solver** out) {
+    if (!cfg || !out) return fail(LBM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(lbm_config))
+        return fail(LBM_ERR_INVALID, "lbm_config.struct_size %u != %zu", cfg->struct_size,
+                    sizeof(lbm_config));
+    if (cfg->N < 1 || cfg->M < 2) return fail(LBM_ERR_INVALID, "need N >= 1 and M >= 2");
+    if (cfg->inner_timesteps < 1 || cfg->inner_timesteps > 64)
+        return fail(LBM_ERR_INVALID, "inner_timesteps must be in [1, 64]");
+    if (cfg->boundary != LBM_BOUNDARY_REFERENCE && cfg->boundary != LBM_BOUNDARY_PERIODIC)
+        return fail(LBM_ERR_INVALID, "unknown boundary %d", cfg->boundary);
+    if (cfg->storage != LBM_STORE_F32 && cfg->storage != LBM_STORE_F16)
+        return fail(LBM_ERR_INVALID, "unknown storage %d", cfg->storage);
+    if (cfg->halo < 0 || cfg->halo > 64) return fail(LBM_ERR_INVALID, "halo must be in [0, 64]");
+    const bool st = cfg->top_edge == LBM_YEDGE_SEAM, sb = cfg->bottom_edge == LBM_YEDGE_SEAM;
+    if ((st || sb) && cfg->halo < 1) return fail(LBM_ERR_INVALID, "a seam edge needs halo >= 1");
+    if ((st || sb) && cfg->N < cfg->halo) return fail(LBM_ERR_INVALID, "N must be >= halo");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(LBM_ERR_INVALID, "device %d out of range (%d HIP devices)", cfg->device, ndev);
+    HIPCHK(hipSetDevice(cfg->device));
+
+    lbm_solver* s = new (std::nothrow) lbm_solver();
+    if (!s) return fail(LBM_ERR_NOMEM, "host allocation failed");
+    memset(s, 0, sizeof *s);
+    s->cfg = *cfg;
+    s->xmode = cfg->boundary == LBM_BOUNDARY_PERIODIC ? XMODE_PERIODIC : XMODE_REFERENCE;
+    s->half = cfg->storage == LBM_STORE_F16;
+    s->T = cfg->inner_timesteps;
+    Geom& g = s->geo;
+    g.N = cfg->N;
+    g.M = cfg->M;
+    g.Mb = (cfg->M + LANES - 1) / LANES;
+    g.G = cfg->halo;
+    g.rowStride = (long long)g.Mb * CHUNK;
+    const int dom = cfg->boundary == LBM_BOUNDARY_PERIODIC ? YEDGE_WRAP : YEDGE_DOMAIN;
+    g.top = st ? YEDGE_GHOST : dom;
+    g.bot = sb ? YEDGE_GHOST : dom;
+    g.omega = cfg->omega;
+    const size_t rows = (size_t)g.N + 2 * (size_t)g.G;
+    s->buf_bytes = rows * (size_t)g.rowStride * elem_size(s);
+    s->mask_bytes = rows * (size_t)g.Mb * sizeof(uint64_t);
+    s->staging_bytes = STAGING_BYTES;
+
+    int rc = LBM_OK;
+    auto bail = [&](hipError_t e, const char* what) {
+        rc = fail(e == hipErrorOutOfMemory ? LBM_ERR_NOMEM : LBM_ERR_HIP, "%s failed: %s", what,
+                  hipGetErrorString(e));
+    };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking)) != hipSuccess) bail(e, "hipStreamCreate");
+    if (rc == LBM_OK && (e = hipMalloc(&s->buf[0], s->buf_bytes)) != hipSuccess) bail(e, "hipMalloc(cells)");
+    if (rc == LBM_OK && (e = hipMalloc(&s->buf[1], s->buf_bytes)) != hipSuccess) bail(e, "hipMalloc(newcells)");
+    if (rc == LBM_OK && (e = hipMalloc((void**)&s->mask, s->mask_bytes)) != hipSuccess) bail(e, "hipMalloc(mask)");
+    if (rc == LBM_OK && (e = hipMalloc(&s->staging, s->staging_bytes)) != hipSuccess) bail(e, "hipMalloc(staging)");
+    if (rc == LBM_OK && (e = hipEventCreate(&s->ev0)) != hipSuccess) bail(e, "hipEventCreate");
+    if (rc == LBM_OK && (e = hipEventCreate(&s->ev1)) != hipSuccess) bail(e, "hipEventCreate");
+    if (rc == LBM_OK && (e = hipMemset(s->buf[0], 0, s->buf_bytes)) != hipSuccess) bail(e, "hipMemset");
+    if (rc == LBM_OK && (e = hipMemset(s->buf[1], 0, s->buf_bytes)) != hipSuccess) bail(e, "hipMemset");
+    if (rc == LBM_OK && (e = hipMemset(s->mask, 0, s->mask_bytes)) != hipSuccess) bail(e, "hipMemset");
+    if (rc != LBM_OK) {
+        lbm_destroy(s);
+        return rc;
+    }
+    s->stream = s->own_stream;
+    *out = s;
+    return LBM_OK;
+}
+
+int lbm_destroy(lbm_solver* s) {
+    if (!s) return LBM_OK;
+    (void)hipSetDevice(s->cfg.device);
+    if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
+    for (int i = 0; i < 2; i++)
+        if (s->buf[i]) (void)hipFree(s->buf[i]);
+    if (s->mask) (void)hipFree(s->mask);
+    if (s->staging) (void)hipFree(s->staging);
+    if (s->frame_dev) (void)hipFree(s->frame_dev);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+    delete s;
+    return LBM_OK;
+}
+
+int lbm_set_stream(lbm_solver* s, void* hip_stream) {
+    ENTER(s);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+    return LBM_OK;
+}
+
+int lbm_set_surroundings(lbm_solver* s, const float surroundings[9]) {
+    ENTER(s);
+    if (!surroundings) return fail(LBM_ERR_INVALID, "surroundings is null");
+    memcpy(s->geo.surr, surroundings, 9 * sizeof(float));
+    return LBM_OK;
+}
+
+static int check_rows(lbm_solver* s, int row0, int nrows, bool ghosts_ok) {
+    const int lo = ghosts_ok ? -s->geo.G : 0, hi = s->geo.N + (ghosts_ok ? s->geo.G : 0);
+    if (nrows < 0 || row0 < lo || (long long)row0 + nrows > hi)
+        return fail(LBM_ERR_INVALID, "rows [%d, %d) outside [%d, %d)", row0, row0 + nrows, lo, hi);
+    return LBM_OK;
+}
+
+int lbm_upload_blocked(lbm_solver* s, const uint8_t* blocked, int row0, int nrows) {
+    ENTER(s);
+    if (!blocked) return fail(LBM_ERR_INVALID, "blocked is null");
+    int rc = check_rows(s, row0, nrows, true);
+    if (rc) return rc;
+    const size_t row_bytes = (size_t)s->geo.M;
+    const int chunk = (int)std::max<size_t>(1, s->staging_bytes / row_bytes);
+    for (int r = 0; r < nrows; r += chunk) {
+        const int n = std::min(chunk, nrows - r);
+        HIPCHK(hipMemcpyAsync(s->staging, blocked + (size_t)r * row_bytes, (size_t)n * row_bytes,
+                              hipMemcpyHostToDevice, s->stream));
+        HIPCHK(launch_import_mask(s->mask, s->geo, (const uint8_t*)s->staging, row0 + r, n, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    return LBM_OK;
+}
+
+int lbm_upload_cells(lbm_solver* s, const float* cells, int row0, int nrows) {
+    ENTER(s);
+    if (!cells) return fail(LBM_ERR_INVALID, "cells is null");
+    int rc = check_rows(s, row0, nrows, true);
+    if (rc) return rc;
+    if (s->pulled) {  // a new initial condition: back to the freshly-uploaded state
+        s->pulled = false;
+        s->steps = 0;
+    }
+    const size_t row_bytes = (size_t)s->geo.M * 9 * sizeof(float);
+    const int chunk = (int)std::max<size_t>(1, s->staging_bytes / row_bytes);
+    if (row_bytes > s->staging_bytes) return fail(LBM_ERR_UNSUPPORTED, "row too long for staging");
+    for (int r = 0; r < nrows; r += chunk) {
+        const int n = std::min(chunk, nrows - r);
+        HIPCHK(hipMemcpyAsync(s->staging, (const char*)cells + (size_t)r * row_bytes,
+                              (size_t)n * row_bytes, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(launch_import_cells(s->buf[s->cur], s->geo, s->half, (const float*)s->staging, row0 + r,
+                                   n, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    return LBM_OK;
+}
+
+int lbm_init_equilibrium(lbm_solver* s, float rho, float u_row, float u_col, float amp, uint64_t seed,
+                         int64_t row_offset, int64_t global_rows) {
+    ENTER(s);
+    s->pulled = false;
+    s->steps = 0;
+    s->ghost_valid = s->geo.G;
+    HIPCHK(launch_init_equilibrium(s->buf[s->cur], s->geo, s->half, rho, u_row, u_col, amp, seed,
+                                   row_offset, global_rows, s->stream));
+    return LBM_OK;
+}
+
+int lbm_init_blocked_discs(lbm_solver* s, int ndiscs, int radius, uint64_t seed, int64_t row_offset,
+                           int64_t global_rows) {
+    ENTER(s);
+    if (ndiscs < 0 || ndiscs > 4096 || radius < 0) return fail(LBM_ERR_INVALID, "bad disc parameters");
+    if (global_rows <= 0) global_rows = s->geo.N;
+    HIPCHK(launch_init_discs(s->mask, s->geo, ndiscs, radius, seed, row_offset, global_rows, s->stream));
+    return LBM_OK;
+}
+
+int lbm_halo_mark_filled(lbm_solver* s) {
+    ENTER(s);
+    s->ghost_valid = s->geo.G;
+    return LBM_OK;
+}
+
+int lbm_halo_valid(lbm_solver* s, int* rows) {
+    ENTER(s);
+    if (!rows) return fail(LBM_ERR_INVALID, "rows is null");
+    *rows = (seam_top(s) || seam_bot(s)) ? s->ghost_valid : 1 << 30;
+    return LBM_OK;
+}
+
+// One update of the numpy-visible state.  Right after an upload the buffer holds f: the first
+// update only collides in place (its stream + reflect half is deferred into the next kernel or
+// into the observers).  Afterwards each update is one fused kernel over the rows whose
+// neighbourhood is still valid.
+static int one_step(lbm_solver* s) {
+    const Geom& g = s->geo;
+    if (!s->pulled) {
+        HIPCHK(launch_collide(s->buf[s->cur], s->mask, g, s->half, -g.G, g.N + 2 * g.G, s->stream));
+        s->pulled = true;
+        s->steps++;
+        return LBM_OK;
+    }
+    const bool seam = seam_top(s) || seam_bot(s);
+    if (seam && s->ghost_valid < 1)
+        return fail(LBM_ERR_INVALID, "ghost rows exhausted: exchange halos (lbm_halo_region) and call "
+                                     "lbm_halo_mark_filled before stepping further");
+    const int ext = seam ? s->ghost_valid - 1 : 0;
+    const int r0 = seam_top(s) ? -ext : 0;
+    const int r1 = g.N + (seam_bot(s) ? ext : 0);
+    HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, r0, r1 - r0,
+                       s->stream));
+    s->cur ^= 1;
+    if (seam) s->ghost_valid--;
+    s->steps++;
+    return LBM_OK;
+}
+
+int lbm_fused_collide_stream(lbm_solver* s, int n_outer) {
+    ENTER(s);
+    if (n_outer < 0) return fail(LBM_ERR_INVALID, "n_outer < 0");
+    for (long long i = 0; i < (long long)n_outer * s->T; i++) {
+        int rc = one_step(s);
+        if (rc) return rc;
+    }
+    return LBM_OK;
+}
+
+int lbm_step_rows(lbm_solver* s, int row0, int nrows, int nsteps) {
+    ENTER(s);
+    int rc = check_rows(s, row0, nrows, true);
+    if (rc) return rc;
+    if (!s->pulled) return fail(LBM_ERR_INVALID, "lbm_step_rows needs a stepped state (call lbm_fused_collide_stream once after upload)");
+    for (int i = 0; i < nsteps; i++) {
+        HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, s->geo, s->xmode, s->half, row0,
+                           nrows, s->stream));
+        s->cur ^= 1;
+        s->steps++;
+    }
+    return LBM_OK;
+}
+
+int lbm_fused_collide_stream_timed(lbm_solver* s, int n_outer, float* elapsed_ms) {
+    ENTER(s);
+    if (!elapsed_ms) return fail(LBM_ERR_INVALID, "elapsed_ms is null");
+    HIPCHK(hipEventRecord(s->ev0, s->stream));
+    int rc = lbm_fused_collide_stream(s, n_outer);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(s->ev1, s->stream));
+    HIPCHK(hipEventSynchronize(s->ev1));
+    HIPCHK(hipEventElapsedTime(elapsed_ms, s->ev0, s->ev1));
+    return LBM_OK;
+}
+
+int lbm_sync(lbm_solver* s) {
+    ENTER(s);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return LBM_OK;
+}
+
+int lbm_steps_done(lbm_solver* s, int64_t* steps) {
+    ENTER(s);
+    if (!steps) return fail(LBM_ERR_INVALID, "steps is null");
+    *steps = s->steps;
+    return LBM_OK;
+}
+
+static int check_window(lbm_solver* s, int row0, int nrows, int col0, int ncols) {
+    int rc = check_rows(s, row0, nrows, false);
+    if (rc) return rc;
+    if (ncols < 0 || col0 < 0 || (long long)col0 + ncols > s->geo.M)
+        return fail(LBM_ERR_INVALID, "columns [%d, %d) outside [0, %d)", col0, col0 + ncols, s->geo.M);
+    if (s->pulled && (seam_top(s) || seam_bot(s)) && s->ghost_valid < 1)
+        return fail(LBM_ERR_INVALID, "ghost rows exhausted: exchange halos before reading back");
+    return LBM_OK;
+}
+
+// Observe a window chunk by chunk through the device staging buffer.
+static int observe(lbm_solver* s, int row0, int nrows, int col0, int ncols, float* cells, float* rho,
+                   float* u, uint8_t* rgb) {
+    if (nrows == 0 || ncols == 0) return LBM_OK;
+    const size_t per_row = (size_t)ncols * ((cells ? 36 : 0) + (rho ? 4 : 0) + (u ? 8 : 0) + (rgb ? 4 : 0));
+    if (per_row == 0) return LBM_OK;
+    if (per_row > s->staging_bytes) return fail(LBM_ERR_UNSUPPORTED, "row too long for staging");
+    const int chunk = (int)std::max<size_t>(1, s->staging_bytes / per_row);
+    for (int r = 0; r < nrows; r += chunk) {
+        const int n = std::min(chunk, nrows - r);
+        char* p = (char*)s->staging;
+        float* dc = nullptr; float* dr = nullptr; float* du = nullptr; uint8_t* dg = nullptr;
+        const size_t cells_n = (size_t)n * ncols;
+        if (cells) { dc = (float*)p; p += cells_n * 36; }
+        if (rho) { dr = (float*)p; p += cells_n * 4; }
+        if (u) { du = (float*)p; p += cells_n * 8; }
+        if (rgb) { dg = (uint8_t*)p; }
+        HIPCHK(launch_observe(s->buf[s->cur], s->mask, s->geo, s->xmode, s->half, s->pulled, row0 + r, n,
+                              col0, ncols, dc, dr, du, dg, s->stream));
+        const size_t o = (size_t)r * ncols;
+        if (cells) HIPCHK(hipMemcpyAsync(cells + o * 9, dc, cells_n * 36, hipMemcpyDeviceToHost, s->stream));
+        if (rho) HIPCHK(hipMemcpyAsync(rho + o, dr, cells_n * 4, hipMemcpyDeviceToHost, s->stream));
+        if (u) HIPCHK(hipMemcpyAsync(u + o * 2, du, cells_n * 8, hipMemcpyDeviceToHost, s->stream));
+        if (rgb) HIPCHK(hipMemcpyAsync(rgb + o * 3, dg, cells_n * 3, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    return LBM_OK;
+}
+
+int lbm_read_cells(lbm_solver* s, float* cells, int row0, int nrows, int col0, int ncols) {
+    ENTER(s);
+    int rc = check_window(s, row0, nrows, col0, ncols);
+    if (rc) return rc;
+    return observe(s, row0, nrows, col0, ncols, cells, nullptr, nullptr, nullptr);
+}
+
+int lbm_read_moments(lbm_solver* s, float* rho, float* u, int row0, int nrows, int col0, int ncols) {
+    ENTER(s);
+    int rc = check_window(s, row0, nrows, col0, ncols);
+    if (rc) return rc;
+    return observe(s, row0, nrows, col0, ncols, nullptr, rho, u, nullptr);
+}
+
+int lbm_read_blocked(lbm_solver* s, uint8_t* blocked, int row0, int nrows) {
+    ENTER(s);
+    if (!blocked) return fail(LBM_ERR_INVALID, "blocked is null");
+    int rc = check_rows(s, row0, nrows, true);
+    if (rc) return rc;
+    const size_t row_bytes = (size_t)s->geo.M;
+    const int chunk = (int)std::max<size_t>(1, s->staging_bytes / row_bytes);
+    for (int r = 0; r < nrows; r += chunk) {
+        const int n = std::min(chunk, nrows - r);
+        HIPCHK(launch_export_mask(s->mask, s->geo, (uint8_t*)s->staging, row0 + r, n, s->stream));
+        HIPCHK(hipMemcpyAsync(blocked + (size_t)r * row_bytes, s->staging, (size_t)n * row_bytes,
+                              hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+    }
+    return LBM_OK;
+}
+
+int lbm_render(lbm_solver* s, uint8_t* rgb, int row0, int nrows) {
+    ENTER(s);
+    if (!rgb) return fail(LBM_ERR_INVALID, "rgb is null");
+    int rc = check_window(s, row0, nrows, 0, s->geo.M);
+    if (rc) return rc;
+    return observe(s, row0, nrows, 0, s->geo.M, nullptr, nullptr, nullptr, rgb);
+}
+
+int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame) {
+    ENTER(s);
+    int rc = lbm_fused_collide_stream(s, 1);
+    if (rc || !frame) return rc;
+    rc = check_window(s, 0, s->geo.N, 0, s->geo.M);
+    if (rc) return rc;
+    const size_t bytes = (size_t)s->geo.N * s->geo.M * 3;
+    if (!s->frame_dev) HIPCHK(hipMalloc((void**)&s->frame_dev, bytes));
+    HIPCHK(launch_observe(s->buf[s->cur], s->mask, s->geo, s->xmode, s->half, s->pulled, 0, s->geo.N, 0,
+                          s->geo.M, nullptr, nullptr, nullptr, s->frame_dev, s->stream));
+    HIPCHK(hipMemcpyAsync(frame, s->frame_dev, bytes, hipMemcpyDeviceToHost, s->stream));
+    return LBM_OK;
+}
+
+int lbm_halo_region(lbm_solver* s, int side, int recv, void** device_ptr, size_t* bytes) {
+    ENTER(s);
+    if (!device_ptr || !bytes || side < 0 || side > 1) return fail(LBM_ERR_INVALID, "bad argument");
+    const Geom& g = s->geo;
+    if (g.G < 1) return fail(LBM_ERR_INVALID, "solver has no halo");
+    // rows in allocation coordinates (row + G)
+    long long r;
+    if (side == 0) r = recv ? 0 : g.G;
+    else r = recv ? g.G + g.N : g.N;  // owned rows [N-G, N) -> allocation rows [N, N+G)
+    *device_ptr = (char*)s->buf[s->cur] + (size_t)r * g.rowStride * elem_size(s);
+    *bytes = (size_t)g.G * g.rowStride * elem_size(s);
+    return LBM_OK;
+}
+
+int lbm_mask_halo_region(lbm_solver* s, int side, int recv, void** device_ptr, size_t* bytes) {
+    ENTER(s);
+    if (!device_ptr || !bytes || side < 0 || side > 1) return fail(LBM_ERR_INVALID, "bad argument");
+    const Geom& g = s->geo;
+    if (g.G < 1) return fail(LBM_ERR_INVALID, "solver has no halo");
+    long long r;
+    if (side == 0) r = recv ? 0 : g.G;
+    else r = recv ? g.G + g.N : g.N;
+    *device_ptr = (char*)s->mask + (size_t)r * g.Mb * sizeof(uint64_t);
+    *bytes = (size_t)g.G * g.Mb * sizeof(uint64_t);
+    return LBM_OK;
+}
+
+}  // extern "C"

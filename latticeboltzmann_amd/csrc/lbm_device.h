@@ -1,0 +1,181 @@
+// Device-side building blocks of the D2Q9 BGK update for gfx950 (wave64).
+//
+// HBM layout (private to the library).  The distribution field is AoSoA with the wavefront as
+// the inner dimension:
+//     field[row + G][xb][slot][lane]      row in [-G, N+G), xb in [0, Mb), slot in [0,9), lane in [0,64)
+// x = 64*xb + lane, G = ghost rows.  One (row, xb) "chunk" is 9*64 elements, contiguous; every
+// wave-level access to one slot is one aligned 256-byte (fp32) line pair.  Slot order is NOT the
+// reference's k order: slot(k) = 3*(dy+1) + (dx+1) with (dy, dx) = e[k] = (k%3-1, k/3-1)
+// (latticeboltzmann.py:30-32), so the three populations a destination row pulls from one source
+// row are adjacent (768 contiguous bytes per source row).
+// The obstacle mask is bit-packed: mask[row + G][xb] is a 64-bit word, bit `lane` = blocked.
+//
+// What is stored is the POST-COLLISION state g = collide(f) (see DESIGN.md "collide-once"): one
+// update is  g' = collide(reflect(pull-stream(g))),  numpy's order being
+// moments, collide, stream, reflect (latticeboltzmann.jl:107-120).
+//
+// Floating point: every expression below is written in the operation order numpy uses for the
+// reference's vectorised path (restated in oracle/lbm_ref.c) and the library is compiled with
+// -ffp-contract=off, so fp32 results are bit-identical to the oracle, not merely within 1e-5.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace lbm {
+
+constexpr int LANES = 64;
+constexpr int Q = 9;
+constexpr int CHUNK = Q * LANES;  // elements per (row, xb) chunk
+
+enum : int { XMODE_REFERENCE = 0, XMODE_PERIODIC = 1 };
+enum : int { YEDGE_DOMAIN = 0, YEDGE_WRAP = 1, YEDGE_GHOST = 2 };
+
+struct Geom {
+    int N;           // owned rows
+    int M;           // columns
+    int Mb;          // ceil(M / 64)
+    int G;           // ghost rows above and below
+    long long rowStride;  // elements per row = Mb * CHUNK
+    int top;         // YEDGE_* for y-1 at y == 0
+    int bot;         // YEDGE_* for y+1 at y == N-1
+    float omega;
+    float surr[9];   // surroundings, reference k order
+};
+
+__host__ __device__ constexpr int slot_of(int k) { return 3 * (k % 3) + k / 3; }
+__host__ __device__ constexpr int dy_of(int k) { return k % 3 - 1; }
+__host__ __device__ constexpr int dx_of(int k) { return k / 3 - 1; }
+
+// --- storage element <-> float ---------------------------------------------------------------
+__device__ __forceinline__ float ld(const float* p) { return *p; }
+__device__ __forceinline__ float ld(const __half* p) { return __half2float(*p); }
+__device__ __forceinline__ void st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st(__half* p, float v) { *p = __float2half_rn(v); }
+
+// --- pull-stream (latticeboltzmann.py:115-120 in pull form) ------------------------------------
+// t[k] = g_k(y - dy, x - dx); where that source is outside the domain:
+//   reference: surroundings[k] if (dx == +1 and x == 0) or (dy == +1 and y == 0), else the
+//              cell's own g_k(y, x)  (the reference's empty `-1:0` slices);
+//   periodic : wrapped source.
+// Seams (YEDGE_GHOST) read the ghost rows.  `y` must be wave-uniform.
+template <int XMODE, typename T>
+__device__ __forceinline__ void pull(const T* __restrict__ g, const Geom& geo, int y, int xb,
+                                     int lane, float t[Q]) {
+    const int M = geo.M;
+    int x = xb * LANES + lane;
+    x = x < M ? x : M - 1;  // padded lanes (x >= M) compute on a valid address; never stored
+    int xm = x + 1;         // source column for dx = -1
+    int xp = x - 1;         // source column for dx = +1
+    bool ob_m = xm >= M, ob_p = xp < 0;
+    if (XMODE == XMODE_PERIODIC) {
+        xm = ob_m ? 0 : xm;
+        xp = ob_p ? M - 1 : xp;
+        ob_m = ob_p = false;
+    }
+    const int off0 = (x >> 6) * CHUNK + (x & 63);
+    const int offm = ob_m ? off0 : (xm >> 6) * CHUNK + (xm & 63);
+    const int offp = ob_p ? off0 : (xp >> 6) * CHUNK + (xp & 63);
+
+    int yu = y - 1, yd = y + 1;  // source rows for dy = +1 / dy = -1
+    bool ob_u = false, ob_d = false;
+    if (y == 0 && geo.top != YEDGE_GHOST) {
+        if (geo.top == YEDGE_WRAP) yu = geo.N - 1; else { ob_u = true; yu = y; }
+    }
+    if (y == geo.N - 1 && geo.bot != YEDGE_GHOST) {
+        if (geo.bot == YEDGE_WRAP) yd = 0; else { ob_d = true; yd = y; }
+    }
+    const T* r0 = g + (long long)(y + geo.G) * geo.rowStride;
+    const T* ru = g + (long long)(yu + geo.G) * geo.rowStride;
+    const T* rd = g + (long long)(yd + geo.G) * geo.rowStride;
+
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
+        const T* rb = dy == 1 ? ru : (dy == 0 ? r0 : rd);
+        const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
+        const int off = dx == 1 ? offp : (dx == 0 ? off0 : offm);
+        const bool ox = dx == 1 ? ob_p : (dx == -1 ? ob_m : false);
+        const T* p = (ox || oy) ? (r0 + off0) : (rb + off);
+        float v = ld(p + sl);
+        const bool inlet = (dx == 1 && ox) || (dy == 1 && oy);
+        t[k] = inlet ? geo.surr[k] : v;
+    }
+}
+
+// --- reflect (latticeboltzmann.py:122-123): k <-> 8-k at blocked cells ------------------------
+__device__ __forceinline__ void reflect(float t[Q], bool blocked) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float a = t[k], b = t[8 - k];
+        t[k] = blocked ? b : a;
+        t[8 - k] = blocked ? a : b;
+    }
+}
+
+// --- moments (latticeboltzmann.py:180-183), numpy's evaluation order ---------------------------
+// np.sum over 9 contiguous floats is pairwise; `cells @ e_f` accumulates k-sequentially and its
+// products by 0 / +-1 are exact, so they are written as adds and subtracts.  u0 = row (y)
+// component, u1 = column (x) component.
+__device__ __forceinline__ float nan_to_num(float v) {
+    v = (v != v) ? 0.0f : v;
+    return (__builtin_fabsf(v) == __builtin_inff()) ? __builtin_copysignf(3.402823466e+38f, v) : v;
+}
+__device__ __forceinline__ void moments(const float a[Q], float& p, float& u0, float& u1) {
+    p = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + a[8];
+    float m0 = 0.0f - a[0];
+    m0 = m0 + a[2]; m0 = m0 - a[3]; m0 = m0 + a[5]; m0 = m0 - a[6]; m0 = m0 + a[8];
+    float m1 = 0.0f - a[0];
+    m1 = m1 - a[1]; m1 = m1 - a[2]; m1 = m1 + a[6]; m1 = m1 + a[7]; m1 = m1 + a[8];
+    u0 = nan_to_num(m0 / p);
+    u1 = nan_to_num(m1 / p);
+}
+
+// --- equilibrium (latticeboltzmann.py:87-89) ---------------------------------------------------
+// eq_k = (p * w_k) * (((1 + 3 eu) + 4.5 eu^2) - 1.5 |u|^2),  eu = u0*dy + u1*dx.
+__device__ __forceinline__ void equilibrium(float u0, float u1, float p, float eq[Q]) {
+    const float W_CORNER = 1.0f / 36, W_AXIS = 1.0f / 9, W_REST = 4.0f / 9;
+    const float c = 1.5f * (u0 * u0 + u1 * u1);
+    const float pc = p * W_CORNER, pa = p * W_AXIS, pr = p * W_REST;
+    const float sp = u0 + u1, sm = u0 - u1;
+    // k and 8-k have opposite eu: share eu^2.
+    // k=0: eu = -(u0+u1), k=8: +(u0+u1)
+    { float q = 4.5f * (sp * sp), h = 3.0f * sp;
+      eq[8] = pc * (((1.0f + h) + q) - c); eq[0] = pc * (((1.0f - h) + q) - c); }
+    // k=1: eu = -u1 (dy=0, dx=-1), k=7: +u1
+    { float q = 4.5f * (u1 * u1), h = 3.0f * u1;
+      eq[7] = pa * (((1.0f + h) + q) - c); eq[1] = pa * (((1.0f - h) + q) - c); }
+    // k=2: eu = u0 - u1 (dy=+1, dx=-1), k=6: -(u0-u1)
+    { float q = 4.5f * (sm * sm), h = 3.0f * sm;
+      eq[2] = pc * (((1.0f + h) + q) - c); eq[6] = pc * (((1.0f - h) + q) - c); }
+    // k=3: eu = -u0 (dy=-1, dx=0), k=5: +u0
+    { float q = 4.5f * (u0 * u0), h = 3.0f * u0;
+      eq[5] = pa * (((1.0f + h) + q) - c); eq[3] = pa * (((1.0f - h) + q) - c); }
+    // k=4: eu = 0:  ((1 + 0) + 0) - c
+    eq[4] = pr * (1.0f - c);
+}
+
+// --- collide (latticeboltzmann.py:107-113 with omega of :98) -----------------------------------
+__device__ __forceinline__ void collide(float a[Q], bool blocked, float omega_free) {
+    float p, u0, u1, eq[Q];
+    moments(a, p, u0, u1);
+    equilibrium(u0, u1, p, eq);
+    const float om = blocked ? 1.0f : omega_free;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        float v = a[k] - eq[k];
+        v = v * om;
+        a[k] = v + eq[k];
+    }
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: workgroups b, b+8, b+16, ... share an XCD
+// (round-robin dispatch), so give each XCD one contiguous band of the tile space and let
+// consecutive workgroups of that XCD walk it in order (neighbouring tiles then share an L2).
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u, idx = b >> 3;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace lbm

@@ -1,0 +1,26 @@
+// Launcher declarations shared by lbm_kernels.hip (device code) and lbm_api.hip (C-ABI host code).
+#pragma once
+#include "lbm_device.h"
+
+namespace lbm {
+
+hipError_t launch_step(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
+                       bool half, int row0, int nrows, hipStream_t st);
+hipError_t launch_collide(void* f, const uint64_t* mask, const Geom& geo, bool half, int row0,
+                          int nrows, hipStream_t st);
+hipError_t launch_observe(const void* g, const uint64_t* mask, const Geom& geo, int xmode, bool half,
+                          bool pulled, int row0, int nrows, int col0, int ncols, float* cells,
+                          float* rho, float* u, uint8_t* rgb, hipStream_t st);
+hipError_t launch_import_cells(void* f, const Geom& geo, bool half, const float* cells, int row0,
+                               int nrows, hipStream_t st);
+hipError_t launch_import_mask(uint64_t* mask, const Geom& geo, const uint8_t* blocked, int row0,
+                              int nrows, hipStream_t st);
+hipError_t launch_export_mask(const uint64_t* mask, const Geom& geo, uint8_t* blocked, int row0,
+                              int nrows, hipStream_t st);
+hipError_t launch_init_equilibrium(void* f, const Geom& geo, bool half, float rho, float u0, float u1,
+                                   float amp, uint64_t seed, long long row_offset, long long wrap_rows,
+                                   hipStream_t st);
+hipError_t launch_init_discs(uint64_t* mask, const Geom& geo, int ndiscs, int radius, uint64_t seed,
+                             long long row_offset, long long global_rows, hipStream_t st);
+
+}  // namespace lbm

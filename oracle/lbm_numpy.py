@@ -1,0 +1,175 @@
+"""CPU oracle (TEST INFRASTRUCTURE, never the product path): numpy restatement of the
+reference's vectorised D2Q9 BGK path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+What it restates (all citations are into /root/reference):
+  constants           latticeboltzmann.py:16-35
+  mask from an image  latticeboltzmann.py:40-41
+  getEquilibrium      latticeboltzmann.py:87-89
+  surroundings        latticeboltzmann.py:92-95
+  omega               latticeboltzmann.py:98
+  collide             latticeboltzmann.py:107-113
+  stream              latticeboltzmann.py:115-120   (incl. the empty `-1:0` slices)
+  reflect             latticeboltzmann.py:122-123
+  initial cells       latticeboltzmann.py:142
+  moments             latticeboltzmann.py:180-183
+  loop order          latticeboltzmann.jl:107-120   (moments, collide, display, stream, reflect)
+  cylinder scene      latticeboltzmann.jl:25-32,51
+
+Pinning status.  The reference cannot be imported here (top-level `import pycuda.autoinit`,
+latticeboltzmann.py:11, and the numpy path is commented out), and it ships no golden fields.
+What the reference itself pins, and tests/test_oracle.py checks: the four lattice asserts
+(:28-29, :33-34), the two conservation asserts (:93-94) and the obstacle masks of its two scene
+images.  FIELD PARITY IS UNPINNED by the reference: the golden fields under tests/golden/ were
+produced by this restatement (tests/golden/make_golden.py).
+
+`boundary="periodic"` has no counterpart in the reference (BASELINE.json configs 2-4 name a
+periodic channel); it replaces the stream step's edge rule by a wrap-around (np.roll).
+"""
+import math
+
+import numpy as np
+
+dtype = np.float32
+rtol = 1e-6  # latticeboltzmann.py:18-21 (fp32 branch)
+
+# Constants for D2Q9 (latticeboltzmann.py:24-35)
+r2 = 3
+w = np.array([1 / 36, 1 / 9, 1 / 36,
+              1 / 9, 4 / 9, 1 / 9,
+              1 / 36, 1 / 9, 1 / 36], dtype=dtype)
+e = np.array([[-1, -1], [0, -1], [1, -1],
+              [-1, 0], [0, 0], [1, 0],
+              [-1, 1], [0, 1], [1, 1]])
+e_f = np.asarray(e, dtype=dtype)
+
+OMEGA = 0.00000000000001  # latticeboltzmann.py:80
+p_ambient = 100           # latticeboltzmann.py:81
+u_ambient = [0, 0.1]      # latticeboltzmann.py:82
+
+
+def lattice_asserts():
+    """The reference's import-time asserts (latticeboltzmann.py:28-29,33-34)."""
+    assert np.all(w == np.flip(w, axis=0))
+    assert math.isclose(sum(w), 1, rel_tol=rtol)
+    assert np.all(e == -np.flip(e, axis=0))
+    assert (np.sum(e, axis=0) == [0, 0]).all()
+
+
+def getEquilibrium(velocity, density):
+    """latticeboltzmann.py:87-89."""
+    eu = velocity @ e_f.T
+    return np.expand_dims(density, -1) * w * (
+        1 + r2 * eu + r2 ** 2 / 2 * np.square(eu)
+        - r2 / 2 * np.expand_dims(np.sum(np.square(velocity), axis=-1), -1))
+
+
+def ambient(p=p_ambient, u=u_ambient):
+    """surroundings / insides, latticeboltzmann.py:92-95 (with its two asserts)."""
+    s = getEquilibrium(np.array([u], dtype=dtype), np.array([p], dtype=dtype))[0]
+    assert np.isclose(sum(s), p, rtol=rtol)
+    assert np.isclose(s @ e_f / p, u, rtol=rtol).all()
+    return s
+
+
+def blocked_from_image(path):
+    """latticeboltzmann.py:40-41."""
+    from PIL import Image
+    return np.array(Image.open(path).convert('L')) > 128
+
+
+def blocked_cylinder(N=400, M=800):
+    """latticeboltzmann.jl:25-32,51: np.fromfunction(isBlocked, (N, M))."""
+    def isBlocked(y, x):
+        return (x - N / 2) ** 2 + (y - N / 2) ** 2 <= (N / 16) ** 2
+    return np.fromfunction(isBlocked, (N, M))
+
+
+def make_omega(blocked, omega_free=OMEGA):
+    """latticeboltzmann.py:98.  float32 so that `cells *= omega` stays float32."""
+    return np.where(np.expand_dims(blocked, -1), np.array(1, ndmin=3),
+                    np.array(omega_free, ndmin=3)).astype(dtype)
+
+
+def initial_cells(blocked, insides):
+    """latticeboltzmann.py:142: every cell (blocked or not) starts at `insides`."""
+    return np.where(np.expand_dims(blocked, -1), np.array(insides, ndmin=3, dtype=dtype),
+                    np.array(insides, ndmin=3, dtype=dtype)).copy()
+
+
+def moments(cells):
+    """latticeboltzmann.py:180-183.  Returns (u (N,M,2) [row, col], p (N,M))."""
+    p = np.sum(cells, axis=2)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        u = cells @ e_f / np.expand_dims(p, -1)
+    np.nan_to_num(u, copy=False)
+    return u, p
+
+
+def collide(cells, u, p, omega):
+    """latticeboltzmann.py:107-113 (in place)."""
+    equilibrium = getEquilibrium(u, p)
+    cells -= equilibrium
+    cells *= omega
+    cells += equilibrium
+
+
+def stream(cells, surroundings):
+    """latticeboltzmann.py:115-120 (in place).  For dx/dy = -1 the fill slice is `-1:0`, which is
+    empty: the last column / last row keep their own post-collision value."""
+    N, M = cells.shape[0], cells.shape[1]
+    for k, (dy, dx) in enumerate(e):
+        cells[max(dy, 0):N + min(dy, 0), max(dx, 0):M + min(dx, 0), k] = \
+            cells[max(-dy, 0):N + min(-dy, 0), max(-dx, 0):M + min(-dx, 0), k]
+        cells[:, min(dx, 0):max(dx, 0), k] = surroundings[k]
+        cells[min(dy, 0):max(dy, 0), :, k] = surroundings[k]
+
+
+def stream_periodic(cells):
+    """No reference counterpart: wrap-around streaming for the periodic-channel configs."""
+    for k, (dy, dx) in enumerate(e):
+        cells[:, :, k] = np.roll(cells[:, :, k], (dy, dx), axis=(0, 1))
+
+
+def reflect(cells, blocked):
+    """latticeboltzmann.py:122-123 (in place)."""
+    cells[blocked] = np.flip(cells[blocked], axis=-1)
+
+
+def step(cells, blocked, omega, surroundings, boundary="reference"):
+    """One timestep in the reference's order (latticeboltzmann.jl:107-120)."""
+    u, p = moments(cells)
+    collide(cells, u, p, omega)
+    if boundary == "reference":
+        stream(cells, surroundings)
+    elif boundary == "periodic":
+        stream_periodic(cells)
+    else:
+        raise ValueError(boundary)
+    reflect(cells, blocked)
+
+
+def run(cells, blocked, steps, omega_free=OMEGA, surroundings=None, boundary="reference"):
+    """Advance `cells` in place by `steps` timesteps; returns cells."""
+    if surroundings is None:
+        surroundings = ambient()
+    omega = make_omega(blocked, omega_free)
+    for _ in range(steps):
+        step(cells, blocked, omega, surroundings, boundary)
+    return cells
+
+
+def perturbed_cells(N, M, seed=0, amp=0.01, p=p_ambient, u=u_ambient):
+    """Bench/parity scene of SURVEY 8(d)(2): equilibrium at (p, u) with a seeded +-amp relative
+    perturbation of the density, so fields are neither constant nor compressible."""
+    rng = np.random.default_rng(seed)
+    rho = (p * (1 + amp * (2 * rng.random((N, M), dtype=np.float32) - 1))).astype(dtype)
+    vel = np.broadcast_to(np.array(u, dtype=dtype), (N, M, 2))
+    return getEquilibrium(vel, rho).astype(dtype)
+
+
+def rel_linf(a, b):
+    """Global-max-normalised L-inf: max|a-b| / max|b| (hard part 1)."""
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))) /
+                 np.max(np.abs(b.astype(np.float64))))

@@ -1,0 +1,25 @@
+"""Quick single-GPU throughput probe (development aid; bench.py is the contract)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from latticeboltzmann_amd.lb_hip_kernel import Solver
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    M = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+    boundary = sys.argv[4] if len(sys.argv) > 4 else "periodic"
+    T = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    s = Solver(N, M, 1e-14, inner_timesteps=T, boundary=boundary)
+    from oracle import lbm_numpy as onp
+    s.set_surroundings(onp.ambient())
+    s.init_equilibrium(100.0, (0.0, 0.1), amp=0.01, seed=0)
+    s.fused_collide_stream(3)
+    s.sync()
+    for rep in range(3):
+        ms = s.fused_collide_stream_timed(steps)
+        glups = N * M * steps * T / ms / 1e6
+        print(f"N={N} M={M} T={T} {boundary}: {ms/steps:.3f} ms/outer  {glups:.2f} GLUPS  {glups*72/1000:.3f} TB/s(72B)  frac={glups*72/8000:.3f}", flush=True)
+    u, rho = s.read_moments(rows=(0, 4), cols=(0, 8))
+    print(rho[0, :4], u[0, :2])
+main()
