@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GLUPS of the fused D2Q9 collide+stream path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+(for N > 1 launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`).
+
+Workload (BASELINE.json configs[1]): fp32 D2Q9, 16384 x 16384 cells per GPU, periodic channel,
+INNER_TIMESTEPS = 1, obstacle-free, state = equilibrium(rho=100, u=[0,0.1]) with a seeded +-1 %
+density perturbation generated on the device.  A "step" is one lattice update of every cell.
+N > 1 is weak scaling: N y-slabs of 16384 rows of one (N*16384) x 16384 periodic domain, 4-deep
+halo exchanged every 4 steps by RCCL send/recv (latticeboltzmann_amd/slabs.py).
+
+One JSON line on rank 0.  `roofline`: the fused kernel's algorithmic bytes (72 B per cell-update,
+/root/reference/latticeboltzmann.py:176) per launch over its average launch time measured with HIP
+events on the solver's stream, against the 8 TB/s HBM peak.  `cpu_baseline`: the oracle's numpy
+path (the reference's vectorised algorithm) timed on this host on a bounded twin of the workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+BYTES_PER_UPDATE = 72   # 9 populations x 4 B read + written
+
+
+def cpu_baseline(budget_s=12.0):
+    """numpy oracle (the reference's vectorised CPU path) and its C twin on a 2048 x 2048 periodic
+    twin of the bench scene; bounded to roughly `budget_s` seconds each."""
+    from oracle import lbm_numpy as onp
+    from oracle import lbm_ref as oc
+    n = 2048
+    cells = onp.perturbed_cells(n, n, seed=0, amp=0.01)
+    blocked = np.zeros((n, n), bool)
+    omega = onp.make_omega(blocked, onp.OMEGA)
+    surr = onp.ambient()
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = 1
+    onp.step(cells, blocked, omega, surr, "periodic")  # warm-up
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        onp.step(cells, blocked, omega, surr, "periodic")
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or steps >= 64:
+            break
+    np_glups = n * n * steps / dt / 1e9
+    out = {"value": np_glups, "unit": "GLUPS", "cores": blas_threads, "kind": "port",
+           "sample": f"oracle/lbm_numpy.py (numpy {np.__version__}; elementwise single-threaded, "
+                     f"BLAS matmul up to {blas_threads} threads), {n}x{n} periodic twin, {steps} steps "
+                     f"in {dt:.1f} s; host has {os.cpu_count()} logical CPUs"}
+    # the C restatement (OpenMP), a fairer CPU figure
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, os.cpu_count() or 1)
+    csteps = 8
+    oc.run(cells, blocked, 1, onp.OMEGA, surr, "periodic")
+    t0 = time.perf_counter()
+    oc.run(cells, blocked, csteps, onp.OMEGA, surr, "periodic")
+    dt = time.perf_counter() - t0
+    out["c_port"] = {"value": n * n * csteps / dt / 1e9, "unit": "GLUPS", "cores": omp,
+                     "sample": f"oracle/lbm_ref.c (OpenMP), same scene, {csteps} steps in {dt:.1f} s"}
+    return out
+
+
+def traffic_per_launch():
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes
+    (profiles/hbm_traffic.json; how it was collected and corrected is in DESIGN.md), or None."""
+    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=16384, help="rows per GPU")
+    ap.add_argument("--cols", type=int, default=16384)
+    ap.add_argument("--halo", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from latticeboltzmann_amd import lb_hip_kernel as hk
+    from latticeboltzmann_amd.slabs import SlabSolver
+    from oracle import lbm_numpy as onp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    rows, cols = args.rows, args.cols
+    surr = onp.ambient()
+    if world == 1:
+        solver = hk.Solver(rows, cols, onp.OMEGA, inner_timesteps=1, boundary="periodic",
+                           device=local_rank)
+        solver.set_surroundings(surr)
+        solver.init_equilibrium(100.0, (0.0, 0.1), amp=0.01, seed=0, row_offset=0, global_rows=rows)
+        solver.fused_collide_stream(args.warmup)
+        solver.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kernel_ms = solver.fused_collide_stream_timed(args.steps)  # HIP events on the solver's stream
+        solver.sync()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        u, rho = solver.read_moments(rows=(0, 8), cols=(0, 64))
+        if not (np.isfinite(rho).all() and np.isfinite(u).all()):
+            raise SystemExit("non-finite fields after the timed region")
+        solver.close()
+    else:
+        slab = SlabSolver(rows * world, cols, onp.OMEGA, rank, world, boundary="periodic",
+                          halo=args.halo, device=local_rank, dist=dist)
+        slab.set_surroundings(surr)
+        slab.init_device_scene(100.0, (0.0, 0.1), amp=0.01, seed=0)
+        slab.step(args.warmup)
+        slab.sync()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(slab.compute)
+        slab.step(args.steps)
+        slab._wait_pending()
+        ev1.record(slab.compute)
+        slab.sync()
+        torch.cuda.synchronize()
+        dist.barrier()
+        wall = time.perf_counter() - t0
+        kernel_ms = ev0.elapsed_time(ev1)
+        t = torch.tensor([wall, kernel_ms], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = float(t[0]), float(t[1])
+        u, rho = slab.read_moments(rows=(0, 8), cols=(0, 64))
+        if not (np.isfinite(rho).all() and np.isfinite(u).all()):
+            raise SystemExit("non-finite fields after the timed region")
+        slab.close()
+
+    if rank == 0:
+        cells = rows * cols
+        glups = cells * world * args.steps / wall / 1e9
+        launch_ms = kernel_ms / args.steps
+        achieved = BYTES_PER_UPDATE * cells / (launch_ms * 1e-3) / 1e9
+        tr = traffic_per_launch() if world == 1 and (rows, cols) == (16384, 16384) else None
+        line = {
+            "metric": "GLUPS (fp32 D2Q9)", "value": glups, "unit": "GLUPS", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"D2Q9 BGK fp32 {rows}x{cols} per GPU, periodic channel, "
+                                   f"INNER_TIMESTEPS=1 (BASELINE.json configs[1])",
+                       "rows_per_gpu": rows, "cols": cols, "inner_timesteps": 1,
+                       "decomposition": "single domain" if world == 1 else
+                                        f"{world} y-slabs, halo {args.halo}, RCCL send/recv every {args.halo} steps"},
+            "frac_of_hbm_roofline": glups * BYTES_PER_UPDATE / (HBM_PEAK_GBS * world),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": tr["bytes_per_launch"] if tr else None,
+                         "kernel": "lbm::step_kernel", "launch_ms": launch_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * cells,
+                         "traffic_source": tr.get("source") if tr else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,9 +116,12 @@ int lbm_fused_collide_stream(lbm_solver* s, int n_outer);
  * buffer uint8 (N, M, 3) as lb_cuda_kernel.cu:27-67,308-319 does; frame == NULL is the plain step,
  * as in latticeboltzmann.py:195-196.  The frame is complete after lbm_sync. */
 int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame);
-/* Exactly `nsteps` updates restricted to rows [row0, row0+nrows) (may extend into ghost rows):
- * the building block of the deep-halo slab schedule. */
-int lbm_step_rows(lbm_solver* s, int row0, int nrows, int nsteps);
+/* One update restricted to rows [row0, row0+nrows) (may extend into ghost rows), written into the
+ * other cell buffer.  finish != 0 ends the update (buffer swap, step count, one ghost row
+ * consumed); finish == 0 leaves it open so that further row ranges of the same update can follow:
+ * the building block of the overlapped slab schedule (edge rows first, interior while the halos
+ * travel). */
+int lbm_step_rows(lbm_solver* s, int row0, int nrows, int finish);
 /* Same as lbm_fused_collide_stream, bracketed by HIP events on the solver's stream; blocks and
  * returns the elapsed device time.  For bench.py's roofline figure. */
 int lbm_fused_collide_stream_timed(lbm_solver* s, int n_outer, float* elapsed_ms);
@@ -139,8 +142,9 @@ int lbm_render(lbm_solver* s, uint8_t* rgb, int row0, int nrows);
 /* --- y-slab halo exchange (no reference code exists, only README.md:12).  The
  * library exposes device pointers; the exchange itself (RCCL send/recv) belongs to the caller.
  * side 0 = top, 1 = bottom.  `send` = the first/last `halo` owned rows of the current state,
- * `recv` = the ghost rows beyond that edge.  Each region is contiguous: *bytes long. --------- */
-int lbm_halo_region(lbm_solver* s, int side, int recv, void** device_ptr, size_t* bytes);
+ * `recv` = the ghost rows beyond that edge; next != 0 addresses the buffer the open update is
+ * writing (see lbm_step_rows) instead of the current one.  Each region is contiguous, *bytes long. */
+int lbm_halo_region(lbm_solver* s, int side, int recv, int next, void** device_ptr, size_t* bytes);
 int lbm_mask_halo_region(lbm_solver* s, int side, int recv, void** device_ptr, size_t* bytes);
 /* Each update consumes one ghost row per seam (the deep halo is recomputed, not re-exchanged):
  * lbm_halo_valid reports how many updates remain before the next exchange is due, and

@@ -296,16 +296,19 @@ int lbm_fused_collide_stream(lbm_solver* s, int n_outer) {
     return LBM_OK;
 }
 
-int lbm_step_rows(lbm_solver* s, int row0, int nrows, int nsteps) {
+int lbm_step_rows(lbm_solver* s, int row0, int nrows, int finish) {
     ENTER(s);
     int rc = check_rows(s, row0, nrows, true);
     if (rc) return rc;
-    if (!s->pulled) return fail(LBM_ERR_INVALID, "lbm_step_rows needs a stepped state (call lbm_fused_collide_stream once after upload)");
-    for (int i = 0; i < nsteps; i++) {
-        HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, s->geo, s->xmode, s->half, row0,
-                           nrows, s->stream));
+    if (!s->pulled)
+        return fail(LBM_ERR_INVALID, "lbm_step_rows needs a stepped state (call "
+                                     "lbm_fused_collide_stream once after an upload)");
+    HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, s->geo, s->xmode, s->half, row0,
+                       nrows, s->stream));
+    if (finish) {
         s->cur ^= 1;
         s->steps++;
+        if ((seam_top(s) || seam_bot(s)) && s->ghost_valid > 0) s->ghost_valid--;
     }
     return LBM_OK;
 }
@@ -427,16 +430,17 @@ int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame) {
     return LBM_OK;
 }
 
-int lbm_halo_region(lbm_solver* s, int side, int recv, void** device_ptr, size_t* bytes) {
+int lbm_halo_region(lbm_solver* s, int side, int recv, int next, void** device_ptr, size_t* bytes) {
     ENTER(s);
     if (!device_ptr || !bytes || side < 0 || side > 1) return fail(LBM_ERR_INVALID, "bad argument");
+    const int b = next ? (s->cur ^ 1) : s->cur;
     const Geom& g = s->geo;
     if (g.G < 1) return fail(LBM_ERR_INVALID, "solver has no halo");
     // rows in allocation coordinates (row + G)
     long long r;
     if (side == 0) r = recv ? 0 : g.G;
     else r = recv ? g.G + g.N : g.N;  // owned rows [N-G, N) -> allocation rows [N, N+G)
-    *device_ptr = (char*)s->buf[s->cur] + (size_t)r * g.rowStride * elem_size(s);
+    *device_ptr = (char*)s->buf[b] + (size_t)r * g.rowStride * elem_size(s);
     *bytes = (size_t)g.G * g.rowStride * elem_size(s);
     return LBM_OK;
 }

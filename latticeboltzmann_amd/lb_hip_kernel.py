@@ -55,6 +55,13 @@ def load_library(path=LIB_PATH):
         raise RuntimeError(
             f"{path} not found: build it with `make -C latticeboltzmann_amd/csrc` "
             "(or __graft_entry__.build()); there is no CPU fallback")
+    # torch wheels bundle their own ROCm runtime; two HIP runtimes in one process cannot both own
+    # the GPU.  If torch is going to be used at all (streams, torch.distributed) it has to be
+    # loaded first, so that this library binds to the runtime that is already there.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(path)
     c_int, c_void_p, c_float = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
     fp = ctypes.POINTER(ctypes.c_float)
@@ -84,7 +91,7 @@ def load_library(path=LIB_PATH):
         "lbm_read_moments": ([H, fp, fp, c_int, c_int, c_int, c_int], c_int),
         "lbm_read_blocked": ([H, bp, c_int, c_int], c_int),
         "lbm_render": ([H, bp, c_int, c_int], c_int),
-        "lbm_halo_region": ([H, c_int, c_int, ctypes.POINTER(c_void_p),
+        "lbm_halo_region": ([H, c_int, c_int, c_int, ctypes.POINTER(c_void_p),
                              ctypes.POINTER(ctypes.c_size_t)], c_int),
         "lbm_mask_halo_region": ([H, c_int, c_int, ctypes.POINTER(c_void_p),
                                   ctypes.POINTER(ctypes.c_size_t)], c_int),
@@ -208,8 +215,9 @@ class Solver:
             assert frame.shape == (self.N, self.M, 3), frame.shape
         _check(self._L.lbm_fused_collide_stream_display(self._h, _bptr(frame)))
 
-    def step_rows(self, row0, nrows, nsteps=1):
-        _check(self._L.lbm_step_rows(self._h, row0, nrows, nsteps))
+    def step_rows(self, row0, nrows, finish):
+        """One update of rows [row0, row0+nrows) into the other buffer; finish=True closes it."""
+        _check(self._L.lbm_step_rows(self._h, row0, nrows, int(bool(finish))))
 
     def fused_collide_stream_timed(self, n_outer):
         """Returns the device time in ms (HIP events on the solver's stream)."""
@@ -259,13 +267,21 @@ class Solver:
         return out
 
     # -- y-slab halos ------------------------------------------------------------------------------
-    def halo_region(self, side, recv, mask=False):
+    def halo_region(self, side, recv, next=False):
         """(device pointer, bytes) of the send (recv=False) or ghost (recv=True) rows at
-        side 0 (top) / 1 (bottom) of the current state (or of the mask)."""
+        side 0 (top) / 1 (bottom) of the current state, or of the buffer an open update is
+        writing (next=True)."""
         p = ctypes.c_void_p()
         n = ctypes.c_size_t()
-        fn = self._L.lbm_mask_halo_region if mask else self._L.lbm_halo_region
-        _check(fn(self._h, side, int(recv), ctypes.byref(p), ctypes.byref(n)))
+        _check(self._L.lbm_halo_region(self._h, side, int(recv), int(next), ctypes.byref(p),
+                                       ctypes.byref(n)))
+        return p.value, n.value
+
+    def mask_halo_region(self, side, recv):
+        p = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        _check(self._L.lbm_mask_halo_region(self._h, side, int(recv), ctypes.byref(p),
+                                            ctypes.byref(n)))
         return p.value, n.value
 
     @property

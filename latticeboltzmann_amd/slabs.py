@@ -1,0 +1,235 @@
+"""y-slab decomposition of one D2Q9 domain over the GPUs of a node, one process per GPU.
+
+No reference code exists for this (the reference is single-GPU; README.md:12 only quotes a
+4-GPU number): SURVEY.md 8(e) defines it.  Rank r owns rows [r*N/P, (r+1)*N/P) plus `halo`
+ghost rows on each seam.  The halo is deep: after one exchange the ghost rows are good for `halo`
+updates (each update recomputes one ghost row less), so neighbours talk once every `halo` steps.
+
+Schedule of one cycle (halo = H), on the compute stream C and the communication stream K:
+    C: H-1 full updates (row range shrinking by one ghost row per update)
+    C: last update, edge rows only: [0, H) and [N-H, N)          -> event E1
+    K: wait E1; grouped send/recv of those rows into the neighbours' ghost rows -> event E2
+    C: last update, interior rows [H, N-H)  (runs while the halos travel)
+    C: wait E2
+The exchange is a grouped torch.distributed send/recv (RCCL over xGMI on the GPU box, gloo in the
+CPU tests): `exchange_halos` below is backend-agnostic and is what tests/test_slabs_gloo.py drives.
+There is no reduction or other collective on the data path.
+"""
+import numpy as np
+
+from . import lb_hip_kernel as hk
+
+
+def slab_rows(global_rows, world, rank):
+    """Row range [lo, hi) of `rank`: equal slabs, the remainder spread over the first ranks."""
+    q, r = divmod(global_rows, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def neighbours(world, rank, boundary):
+    """(up, down) ranks across the top / bottom seam, None at a true domain edge."""
+    if world == 1:
+        return None, None
+    if boundary == "periodic":
+        return (rank - 1) % world, (rank + 1) % world
+    return (rank - 1 if rank > 0 else None), (rank + 1 if rank < world - 1 else None)
+
+
+def exchange_halos(dist, send_top, send_bot, recv_top, recv_bot, up, down, group=None):
+    """Post one grouped exchange; returns the list of work handles (call .wait() on each).
+
+    send_top/send_bot: my first/last `halo` owned rows; recv_top/recv_bot: my ghost rows.
+    Order matters when up == down (two ranks, periodic): both sides send [top, bottom], so the
+    first message I receive from that peer is ITS top rows, which are my BOTTOM ghost rows.
+    """
+    ops = []
+    if up is not None:
+        ops.append(dist.P2POp(dist.isend, send_top, up, group))
+    if down is not None:
+        ops.append(dist.P2POp(dist.isend, send_bot, down, group))
+    if down is not None:
+        ops.append(dist.P2POp(dist.irecv, recv_bot, down, group))
+    if up is not None:
+        ops.append(dist.P2POp(dist.irecv, recv_top, up, group))
+    if not ops:
+        return []
+    return dist.batch_isend_irecv(ops)
+
+
+def advance(b, n):
+    """The slab schedule (module docstring) over a backend `b` that provides is_fresh(),
+    halo_valid(), full_updates(k), edge_update(), exchange(), interior_update().  SlabSolver is the
+    GPU backend; tests/test_slabs_gloo.py drives the same function with a numpy backend."""
+    while n > 0:
+        if b.is_fresh():  # first update after an upload only collides: consumes no ghost row
+            b.full_updates(1)
+            n -= 1
+            continue
+        hv = b.halo_valid()
+        if hv > 1:
+            k = min(n, hv - 1)
+            b.full_updates(k)
+            n -= k
+            continue
+        b.edge_update()      # last update of the cycle: rows the neighbours need, first
+        b.exchange()         # ... travel on the communication stream ...
+        b.interior_update()  # ... while the interior rows are updated
+        n -= 1
+
+
+class _DevMem:
+    """Raw device memory exposed through __cuda_array_interface__ so torch can wrap it."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {
+            "shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2, "strides": None}
+
+
+class SlabSolver:
+    """One rank's slab.  torch is used for streams, events and torch.distributed only."""
+
+    def __init__(self, global_rows, M, omega, rank, world, boundary="periodic", halo=4,
+                 dtype=np.float32, device=None, dist=None, group=None, host_staged=None):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.group = group
+        self.rank, self.world, self.boundary = rank, world, boundary
+        self.global_rows, self.M = global_rows, M
+        self.row_lo, self.row_hi = slab_rows(global_rows, world, rank)
+        self.N = self.row_hi - self.row_lo
+        self.up, self.down = neighbours(world, rank, boundary)
+        self.halo = halo if world > 1 else 0
+        if world > 1 and self.N < 2 * halo:
+            raise ValueError(f"slab of {self.N} rows is too thin for halo {halo}")
+        self.device = torch.cuda.current_device() if device is None else device
+        self.solver = hk.Solver(
+            self.N, M, omega, boundary=boundary, dtype=dtype, device=self.device, halo=self.halo,
+            top_edge=hk.YEDGE_SEAM if self.up is not None else hk.YEDGE_DOMAIN,
+            bottom_edge=hk.YEDGE_SEAM if self.down is not None else hk.YEDGE_DOMAIN)
+        self.compute = torch.cuda.Stream(device=self.device)
+        self.comm = torch.cuda.Stream(device=self.device)
+        self.solver.set_stream(self.compute.cuda_stream)
+        self._tensors = {}
+        self._fresh = True
+        self._pending = None  # event the compute stream must wait for before the next update
+        # gloo cannot send/recv device memory: stage the halos through the host (no overlap).
+        # Only for rehearsing several ranks on one GPU; RCCL moves device memory directly.
+        if host_staged is None:
+            host_staged = world > 1 and dist is not None and dist.get_backend(group) == "gloo"
+        self.host_staged = host_staged
+
+    # -- scene -------------------------------------------------------------------------------------
+    def set_surroundings(self, surroundings):
+        self.solver.set_surroundings(surroundings)
+
+    def init_device_scene(self, rho, u, amp=0.01, seed=0, ndiscs=0, radius=0):
+        """Synthetic scene generated on the device, consistent across ranks (ghost rows included)."""
+        wrap = self.global_rows if self.boundary == "periodic" else 0
+        self.solver.init_equilibrium(rho, u, amp, seed, self.row_lo, wrap)
+        self.solver.init_blocked_discs(ndiscs, radius, seed + 1, self.row_lo, self.global_rows)
+        self._fresh = True
+
+    def upload_global(self, cells, blocked):
+        """Cut this rank's slab (with ghost rows) out of host arrays of the whole domain."""
+        H = self.halo
+        rows = np.arange(self.row_lo - H, self.row_hi + H)
+        if self.boundary == "periodic":
+            rows = rows % self.global_rows
+        else:
+            rows = np.clip(rows, 0, self.global_rows - 1)  # beyond a domain edge: never read
+        self.solver.upload_blocked(np.ascontiguousarray(blocked[rows]), -H)
+        self.solver.upload_cells(np.ascontiguousarray(cells[rows]), -H)
+        self.solver.halo_mark_filled()
+        self._fresh = True
+
+    # -- stepping ----------------------------------------------------------------------------------
+    def _wrap(self, ptr, nbytes):
+        t = self._tensors.get(ptr)
+        if t is None:
+            t = self.torch.as_tensor(_DevMem(ptr, nbytes), device=f"cuda:{self.device}")
+            self._tensors[ptr] = t
+        return t
+
+    def _wait_pending(self):
+        if self._pending is not None:
+            self.compute.wait_event(self._pending)
+            self._pending = None
+
+    def step(self, n=1):
+        """Advance by n updates (asynchronous)."""
+        if self.world == 1:
+            self.solver.fused_collide_stream(n)
+            return
+        advance(self, n)
+
+    # backend protocol of `advance` -------------------------------------------------------------
+    def is_fresh(self):
+        return self._fresh
+
+    def halo_valid(self):
+        return self.solver.halo_valid
+
+    def full_updates(self, k):
+        self._wait_pending()
+        self.solver.fused_collide_stream(k)
+        self._fresh = False
+
+    def edge_update(self):
+        self._wait_pending()
+        self.solver.step_rows(0, self.halo, False)
+        self.solver.step_rows(self.N - self.halo, self.halo, False)
+
+    def exchange(self):
+        torch, s = self.torch, self.solver
+        e1 = torch.cuda.Event()
+        e1.record(self.compute)
+        ptrs = [s.halo_region(0, False, next=True), s.halo_region(1, False, next=True),
+                s.halo_region(0, True, next=True), s.halo_region(1, True, next=True)]
+        st, sb, rt, rb = (self._wrap(p, b) for p, b in ptrs)
+        if self.host_staged:
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(e1)
+                hst, hsb = st.cpu(), sb.cpu()  # synchronous D2H on the comm stream
+                hrt, hrb = torch.empty_like(hst), torch.empty_like(hsb)
+                for w in exchange_halos(self.dist, hst, hsb, hrt, hrb, self.up, self.down, self.group):
+                    w.wait()
+                if self.up is not None:
+                    rt.copy_(hrt)
+                if self.down is not None:
+                    rb.copy_(hrb)
+                e2 = torch.cuda.Event()
+                e2.record(self.comm)
+            self._pending = e2
+            return
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(e1)
+            for w in exchange_halos(self.dist, st, sb, rt, rb, self.up, self.down, self.group):
+                w.wait()
+            e2 = torch.cuda.Event()
+            e2.record(self.comm)
+        self._pending = e2
+
+    def interior_update(self):
+        # not ordered after the exchange: it runs while the halos travel
+        self.solver.step_rows(self.halo, self.N - 2 * self.halo, True)
+        self.solver.halo_mark_filled()
+
+    def sync(self):
+        self._wait_pending()
+        self.compute.synchronize()
+        self.comm.synchronize()
+
+    # -- readback (this rank's rows) ---------------------------------------------------------------
+    def read_moments(self, rows=None, cols=None):
+        self.sync()
+        return self.solver.read_moments(rows, cols)
+
+    def read_cells(self, rows=None, cols=None):
+        self.sync()
+        return self.solver.read_cells(rows, cols)
+
+    def close(self):
+        self.sync()
+        self.solver.close()
