@@ -116,6 +116,10 @@ int lbm_fused_collide_stream(lbm_solver* s, int n_outer);
  * buffer uint8 (N, M, 3) as lb_cuda_kernel.cu:27-67,308-319 does; frame == NULL is the plain step,
  * as in latticeboltzmann.py:195-196.  The frame is complete after lbm_sync. */
 int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame);
+/* Tuning of the INNER_TIMESTEPS > 1 path (replaces the reference's per-GPU presets,
+ * latticeboltzmann.py:55-71): deepest temporal-blocking launch (1..4; inner_timesteps is split
+ * into balanced launches no deeper than this; 1 = plain kernel only) and rows per workgroup. */
+int lbm_set_tuning(lbm_solver* s, int tb_max_depth, int tb_rows);
 /* One update restricted to rows [row0, row0+nrows) (may extend into ghost rows), written into the
  * other cell buffer.  finish != 0 ends the update (buffer swap, step count, one ghost row
  * consumed); finish == 0 leaves it open so that further row ranges of the same update can follow:

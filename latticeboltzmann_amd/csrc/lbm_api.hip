@@ -35,6 +35,8 @@ struct lbm_solver {
     int xmode;
     bool half;
     int T;
+    int tb_max;   // deepest temporal-blocking launch (1 = never use the LDS kernel)
+    int tb_rows;  // rows per workgroup chunk of the LDS kernel
     hipStream_t own_stream, stream;
     void* buf[2];
     size_t buf_bytes;
@@ -109,6 +111,8 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     s->xmode = cfg->boundary == LBM_BOUNDARY_PERIODIC ? XMODE_PERIODIC : XMODE_REFERENCE;
     s->half = cfg->storage == LBM_STORE_F16;
     s->T = cfg->inner_timesteps;
+    s->tb_max = TB_MAX_T;
+    s->tb_rows = 256;
     Geom& g = s->geo;
     g.N = cfg->N;
     g.M = cfg->M;
@@ -259,40 +263,81 @@ int lbm_halo_valid(lbm_solver* s, int* rows) {
     return LBM_OK;
 }
 
-// One update of the numpy-visible state.  Right after an upload the buffer holds f: the first
-// update only collides in place (its stream + reflect half is deferred into the next kernel or
-// into the observers).  Afterwards each update is one fused kernel over the rows whose
-// neighbourhood is still valid.
-static int one_step(lbm_solver* s) {
+// Advance the numpy-visible state by `total` updates.  Right after an upload the buffer holds f:
+// the first update only collides in place (its stream + reflect half is deferred into the next
+// kernel or into the observers).  Afterwards updates go in launches of depth t <= max_depth:
+// t = 1 is the plain fused kernel, t > 1 the LDS temporal-blocking kernel (lbm_tb.hip).  At a
+// seam each update consumes one ghost row.
+static int advance(lbm_solver* s, long long total, int max_depth) {
     const Geom& g = s->geo;
-    if (!s->pulled) {
-        HIPCHK(launch_collide(s->buf[s->cur], s->mask, g, s->half, -g.G, g.N + 2 * g.G, s->stream));
-        s->pulled = true;
-        s->steps++;
-        return LBM_OK;
-    }
     const bool seam = seam_top(s) || seam_bot(s);
-    if (seam && s->ghost_valid < 1)
-        return fail(LBM_ERR_INVALID, "ghost rows exhausted: exchange halos (lbm_halo_region) and call "
-                                     "lbm_halo_mark_filled before stepping further");
-    const int ext = seam ? s->ghost_valid - 1 : 0;
-    const int r0 = seam_top(s) ? -ext : 0;
-    const int r1 = g.N + (seam_bot(s) ? ext : 0);
-    HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, r0, r1 - r0,
-                       s->stream));
-    s->cur ^= 1;
-    if (seam) s->ghost_valid--;
-    s->steps++;
+    while (total > 0) {
+        if (!s->pulled) {
+            HIPCHK(launch_collide(s->buf[s->cur], s->mask, g, s->half, -g.G, g.N + 2 * g.G, s->stream));
+            s->pulled = true;
+            s->steps++;
+            total--;
+            continue;
+        }
+        if (seam && s->ghost_valid < 1)
+            return fail(LBM_ERR_INVALID, "ghost rows exhausted: exchange halos (lbm_halo_region) and "
+                                         "call lbm_halo_mark_filled before stepping further");
+        int t = (int)std::min<long long>(total, max_depth);
+        if (seam) t = std::min(t, s->ghost_valid);
+        if (g.M < 8 || g.N < 8) t = 1;  // tiny domains: the strip pipeline is not worth its edge cases
+        const int ext = seam ? s->ghost_valid - t : 0;
+        const int r0 = seam_top(s) ? -ext : 0;
+        const int r1 = g.N + (seam_bot(s) ? ext : 0);
+        if (t == 1)
+            HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, r0,
+                               r1 - r0, s->stream));
+        else
+            HIPCHK(launch_step_tb(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, t,
+                                  r0, r1 - r0, s->tb_rows, s->stream));
+        s->cur ^= 1;
+        if (seam) s->ghost_valid -= t;
+        s->steps += t;
+        total -= t;
+    }
+    return LBM_OK;
+}
+
+// One outer iteration = inner_timesteps updates, split into ceil(T / depth_cap) balanced launches
+// (e.g. T = 6 -> 3 + 3).
+static int outer_iteration(lbm_solver* s) {
+    int rem = s->T;
+    if (!s->pulled) {
+        int rc = advance(s, 1, 1);
+        if (rc) return rc;
+        rem--;
+    }
+    if (rem <= 0) return LBM_OK;
+    const int cap = std::max(1, std::min(s->tb_max, TB_MAX_T));
+    const int nl = (rem + cap - 1) / cap;
+    for (int i = 0; i < nl; i++) {
+        const int t = rem / nl + (i < rem % nl ? 1 : 0);
+        int rc = advance(s, t, t);
+        if (rc) return rc;
+    }
     return LBM_OK;
 }
 
 int lbm_fused_collide_stream(lbm_solver* s, int n_outer) {
     ENTER(s);
     if (n_outer < 0) return fail(LBM_ERR_INVALID, "n_outer < 0");
-    for (long long i = 0; i < (long long)n_outer * s->T; i++) {
-        int rc = one_step(s);
+    for (int i = 0; i < n_outer; i++) {
+        int rc = outer_iteration(s);
         if (rc) return rc;
     }
+    return LBM_OK;
+}
+
+int lbm_set_tuning(lbm_solver* s, int tb_max_depth, int tb_rows) {
+    ENTER(s);
+    if (tb_max_depth < 1 || tb_max_depth > TB_MAX_T || tb_rows < 1)
+        return fail(LBM_ERR_INVALID, "tb_max_depth must be in [1, %d] and tb_rows >= 1", TB_MAX_T);
+    s->tb_max = tb_max_depth;
+    s->tb_rows = tb_rows;
     return LBM_OK;
 }
 

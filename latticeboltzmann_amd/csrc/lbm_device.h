@@ -52,6 +52,11 @@ __device__ __forceinline__ float ld(const float* p) { return *p; }
 __device__ __forceinline__ float ld(const __half* p) { return __half2float(*p); }
 __device__ __forceinline__ void st(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st(__half* p, float v) { *p = __float2half_rn(v); }
+// streaming (non-temporal) store: the new state is not re-read before the next launch
+__device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_nt(__half* p, float v) {
+    __builtin_nontemporal_store(__half_as_ushort(__float2half_rn(v)), reinterpret_cast<unsigned short*>(p));
+}
 
 // --- pull-stream (latticeboltzmann.py:115-120 in pull form) ------------------------------------
 // t[k] = g_k(y - dy, x - dx); where that source is outside the domain:

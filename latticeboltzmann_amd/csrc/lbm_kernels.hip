@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void step_kernel(const T* __restrict__ gin, T*
     if (xb * LANES + lane < geo.M) {
         T* o = gout + (long long)(y + geo.G) * geo.rowStride + (long long)xb * CHUNK + lane;
 #pragma unroll
-        for (int k = 0; k < Q; k++) st(o + slot_of(k) * LANES, a[k]);
+        for (int k = 0; k < Q; k++) st_nt(o + slot_of(k) * LANES, a[k]);
     }
 }
 

@@ -29,7 +29,7 @@ SYMBOLS = [
     "lbm_fused_collide_stream_display", "lbm_step_rows", "lbm_fused_collide_stream_timed",
     "lbm_sync", "lbm_steps_done", "lbm_read_cells", "lbm_read_moments", "lbm_read_blocked",
     "lbm_render", "lbm_halo_region", "lbm_mask_halo_region", "lbm_halo_valid",
-    "lbm_halo_mark_filled",
+    "lbm_halo_mark_filled", "lbm_set_tuning",
 ]
 
 
@@ -97,6 +97,7 @@ def load_library(path=LIB_PATH):
                                   ctypes.POINTER(ctypes.c_size_t)], c_int),
         "lbm_halo_valid": ([H, ctypes.POINTER(c_int)], c_int),
         "lbm_halo_mark_filled": ([H], c_int),
+        "lbm_set_tuning": ([H, c_int, c_int], c_int),
     }
     assert set(protos) == set(SYMBOLS)
     for name, (argtypes, restype) in protos.items():
@@ -214,6 +215,9 @@ class Solver:
             assert frame.dtype == np.uint8 and frame.flags.c_contiguous
             assert frame.shape == (self.N, self.M, 3), frame.shape
         _check(self._L.lbm_fused_collide_stream_display(self._h, _bptr(frame)))
+
+    def set_tuning(self, tb_max_depth=4, tb_rows=256):
+        _check(self._L.lbm_set_tuning(self._h, tb_max_depth, tb_rows))
 
     def step_rows(self, row0, nrows, finish):
         """One update of rows [row0, row0+nrows) into the other buffer; finish=True closes it."""

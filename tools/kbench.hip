@@ -1,0 +1,175 @@
+// Development micro-benchmark: variants of the T=1 fused kernel timed interleaved in ONE process
+// (cdna_hip_programming.md 5.4 rule 24).  Not part of the product; build: make -C tools kbench.
+// Scene: periodic, obstacle-free mask (all zero), perturbed equilibrium.  Every variant computes
+// the same update; a checksum of a few cells is printed so that a broken variant shows.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include "../latticeboltzmann_amd/csrc/lbm_device.h"
+
+using namespace lbm;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+enum { F_NT_ST = 1, F_NT_LD = 2, F_NO_REMAP = 4, F_ROWS4 = 8, F_PERSIST = 16, F_TWO = 32 };
+
+template <int FLAGS>
+__device__ __forceinline__ float ldx(const float* p) {
+    if (FLAGS & F_NT_LD) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <int FLAGS>
+__device__ __forceinline__ void stx(float* p, float v) {
+    if (FLAGS & F_NT_ST) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// periodic pull, fp32
+template <int FLAGS>
+__device__ __forceinline__ void pullp(const float* __restrict__ g, const Geom& geo, int y, int xb, int lane, float t[Q]) {
+    const int M = geo.M;
+    int x = xb * LANES + lane;
+    int xm = x + 1; xm = xm >= M ? 0 : xm;
+    int xp = x - 1; xp = xp < 0 ? M - 1 : xp;
+    const int off0 = xb * CHUNK + lane;
+    const int offm = (xm >> 6) * CHUNK + (xm & 63);
+    const int offp = (xp >> 6) * CHUNK + (xp & 63);
+    int yu = y == 0 ? geo.N - 1 : y - 1;
+    int yd = y == geo.N - 1 ? 0 : y + 1;
+    const float* r0 = g + (long long)y * geo.rowStride;
+    const float* ru = g + (long long)yu * geo.rowStride;
+    const float* rd = g + (long long)yd * geo.rowStride;
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
+        const float* rb = dy == 1 ? ru : (dy == 0 ? r0 : rd);
+        const int off = dx == 1 ? offp : (dx == 0 ? off0 : offm);
+        t[k] = ldx<FLAGS>(rb + off + sl);
+    }
+}
+
+template <int FLAGS>
+__device__ __forceinline__ void do_tile(const float* __restrict__ gin, float* __restrict__ gout,
+                                        const uint64_t* __restrict__ mask, const Geom& geo, int y, int xb, int lane) {
+    float a[Q];
+    pullp<FLAGS>(gin, geo, y, xb, lane, a);
+    const uint64_t mrow = mask[(long long)y * geo.Mb + xb];
+    const bool blocked = (mrow >> lane) & 1ull;
+    reflect(a, blocked);
+    collide(a, blocked, geo.omega);
+    float* o = gout + (long long)y * geo.rowStride + (long long)xb * CHUNK + lane;
+#pragma unroll
+    for (int k = 0; k < Q; k++) stx<FLAGS>(o + slot_of(k) * LANES, a[k]);
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256) void kvar(const float* __restrict__ gin, float* __restrict__ gout,
+                                            const uint64_t* __restrict__ mask, Geom geo) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const long long ntiles = (long long)geo.N * geo.Mb;
+    if (FLAGS & F_PERSIST) {
+        // each workgroup owns a contiguous span of tiles
+        const long long per = (ntiles / 4 + gridDim.x - 1) / gridDim.x;  // wg-tiles (4 tiles each)
+        const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+        long long t0 = (long long)wg * per, t1 = std::min<long long>(t0 + per, ntiles / 4);
+        for (long long t = t0; t < t1; t++) {
+            const long long tile = t * 4 + wave;
+            do_tile<FLAGS>(gin, gout, mask, geo, (int)(tile / geo.Mb), (int)(tile % geo.Mb), lane);
+        }
+        return;
+    }
+    const unsigned wg = (FLAGS & F_NO_REMAP) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    if (FLAGS & F_TWO) {
+        // a wave does two vertically adjacent tiles (18 loads in flight)
+        const long long t = (long long)wg * 4 + wave;  // index over (N/2) x Mb
+        const int y = 2 * (int)(t / geo.Mb), xb = (int)(t % geo.Mb);
+        float a[Q], b[Q];
+        pullp<FLAGS>(gin, geo, y, xb, lane, a);
+        pullp<FLAGS>(gin, geo, y + 1, xb, lane, b);
+        const bool bl0 = (mask[(long long)y * geo.Mb + xb] >> lane) & 1ull;
+        const bool bl1 = (mask[(long long)(y + 1) * geo.Mb + xb] >> lane) & 1ull;
+        reflect(a, bl0); collide(a, bl0, geo.omega);
+        reflect(b, bl1); collide(b, bl1, geo.omega);
+        float* o = gout + (long long)y * geo.rowStride + (long long)xb * CHUNK + lane;
+#pragma unroll
+        for (int k = 0; k < Q; k++) stx<FLAGS>(o + slot_of(k) * LANES, a[k]);
+        o += geo.rowStride;
+#pragma unroll
+        for (int k = 0; k < Q; k++) stx<FLAGS>(o + slot_of(k) * LANES, b[k]);
+        return;
+    }
+    int y, xb;
+    if (FLAGS & F_ROWS4) {
+        // workgroup = 4 rows x 1 xb
+        const long long t = wg;  // over (N/4) x Mb
+        y = 4 * (int)(t / geo.Mb) + wave; xb = (int)(t % geo.Mb);
+    } else {
+        const long long tile = (long long)wg * 4 + wave;
+        y = (int)(tile / geo.Mb); xb = (int)(tile % geo.Mb);
+    }
+    do_tile<FLAGS>(gin, gout, mask, geo, y, xb, lane);
+}
+
+__global__ void initk(float* f, Geom geo) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)geo.N * geo.rowStride;
+    if (i >= n) return;
+    const int slot = (int)((i / 64) % 9);
+    const float base[9] = {2.03f, 10.9f, 3.69f, 8.11f, 43.8f, 14.8f, 2.03f, 10.9f, 3.69f};
+    unsigned h = (unsigned)(i * 2654435761u); h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    f[i] = base[slot] * (1.0f + 0.01f * ((h & 0xffff) / 32768.0f - 1.0f));
+}
+
+struct Var { const char* name; void (*fn)(const float*, float*, const uint64_t*, Geom); int div; bool persist; };
+
+template <int FLAGS> static Var mk(const char* n) {
+    return Var{n, kvar<FLAGS>, (FLAGS & F_TWO) ? 2 : 1, (FLAGS & F_PERSIST) != 0};
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 16384, M = argc > 2 ? atoi(argv[2]) : 16384;
+    const int rounds = argc > 3 ? atoi(argv[3]) : 5, reps = 10;
+    Geom geo{};
+    geo.N = N; geo.M = M; geo.Mb = M / 64; geo.G = 0; geo.rowStride = (long long)geo.Mb * CHUNK;
+    geo.top = geo.bot = YEDGE_WRAP; geo.omega = 1e-14f;
+    const size_t bytes = (size_t)N * geo.rowStride * 4;
+    float *a, *b; uint64_t* mask;
+    CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes));
+    CHECK(hipMalloc(&mask, (size_t)N * geo.Mb * 8)); CHECK(hipMemset(mask, 0, (size_t)N * geo.Mb * 8));
+    hipLaunchKernelGGL(initk, dim3((unsigned)(((long long)N * geo.rowStride + 255) / 256)), dim3(256), 0, 0, a, geo);
+    CHECK(hipDeviceSynchronize());
+    std::vector<Var> vars = {
+        mk<0>("base"), mk<F_NT_ST>("nt_store"), mk<F_NT_ST | F_NT_LD>("nt_both"), mk<F_NT_LD>("nt_load"),
+        mk<F_NO_REMAP>("no_remap"), mk<F_ROWS4>("rows4"), mk<F_ROWS4 | F_NT_ST>("rows4_ntst"),
+        mk<F_PERSIST>("persist"), mk<F_TWO>("two_rows"), mk<F_TWO | F_NT_ST>("two_rows_ntst"),
+    };
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    std::vector<std::vector<float>> ms(vars.size());
+    const long long ntiles = (long long)N * geo.Mb;
+    for (int r = 0; r < rounds + 1; r++) {
+        for (size_t v = 0; v < vars.size(); v++) {
+            unsigned grid = vars[v].persist ? 256 * 8 : (unsigned)(ntiles / 4 / vars[v].div);
+            CHECK(hipEventRecord(e0, 0));
+            for (int i = 0; i < reps; i++) {
+                hipLaunchKernelGGL(vars[v].fn, dim3(grid), dim3(256), 0, 0, (const float*)a, b, (const uint64_t*)mask, geo);
+                std::swap(a, b);
+            }
+            CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+            float t; CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (r > 0) ms[v].push_back(t / reps);
+        }
+    }
+    float chk[4]; CHECK(hipMemcpy(chk, a + 12345 * 64, sizeof chk, hipMemcpyDeviceToHost));
+    printf("check %g %g %g %g\n", chk[0], chk[1], chk[2], chk[3]);
+    const double cells = (double)N * M;
+    for (size_t v = 0; v < vars.size(); v++) {
+        std::sort(ms[v].begin(), ms[v].end());
+        float med = ms[v][ms[v].size() / 2], mn = ms[v][0];
+        printf("%-16s median %.3f ms  min %.3f ms  %.2f GLUPS  %.3f TB/s\n", vars[v].name, med, mn,
+               cells / med / 1e6, cells * 72 / med / 1e9);
+    }
+    return 0;
+}
