@@ -284,7 +284,7 @@ static int advance(lbm_solver* s, long long total, int max_depth) {
                                          "call lbm_halo_mark_filled before stepping further");
         int t = (int)std::min<long long>(total, max_depth);
         if (seam) t = std::min(t, s->ghost_valid);
-        if (g.M < 8 || g.N < 8) t = 1;  // tiny domains: the strip pipeline is not worth its edge cases
+        if (g.M < 8 || g.N < 16) t = 1;  // tiny domains: rows wrap at most once in the strip pipeline
         const int ext = seam ? s->ghost_valid - t : 0;
         const int r0 = seam_top(s) ? -ext : 0;
         const int r1 = g.N + (seam_bot(s) ? ext : 0);

@@ -20,6 +20,8 @@
 // cell-update = 72/T (+ halo columns and 3(T-1) warm-up rows per chunk).  Every cell goes through
 // the same pull/reflect/collide device functions as the T=1 kernel, so results are bit-identical
 // to T single updates.
+#include <type_traits>
+
 #include "lbm_internal.h"
 
 namespace lbm {
@@ -33,14 +35,21 @@ struct TB {
     static constexpr int LEVF = 4 * ROWF;        // floats per level (ring of 4 rows)
     static constexpr int LDSF = (T - 1) * LEVF;
     static constexpr int NW = T * (NB + 1) - 1;  // waves: NB main per stage + a halo wave for s < T
+    static constexpr int FROWS = 16;             // ring depth of the blocked-flag rows (> 2(T-1)+1)
 };
 
+// All loads in the row loops are unconditional and straight-line (rows outside a stage's range
+// are clamped to a valid row instead of skipped), so that hipcc can use counted s_waitcnt vmcnt(N)
+// and the stage-1 prefetch really stays in flight across two iterations and barriers.
 template <int XMODE, int T, int NB, typename ST>
 __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
     const ST* __restrict__ gin, ST* __restrict__ gout, const uint64_t* __restrict__ mask, Geom geo,
     int row0, int nrows, int Ry, int nstrips) {
     using C = TB<T, NB>;
     __shared__ float lds[C::LDSF];
+    // blocked flags of level-1 cells, written by stage 1 and read by the later stages, so that
+    // only stage 1 loads the bit-packed mask from global memory
+    __shared__ uint8_t flags[C::FROWS * C::RW];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -53,13 +62,15 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
     const bool wrapy = geo.top == YEDGE_WRAP;  // top and bottom wrap together
     const int qlo = geo.top == YEDGE_DOMAIN ? 0 : -(1 << 28);  // rows that exist
     const int qhi = geo.bot == YEDGE_DOMAIN ? N : (1 << 28);
+    const long long RS = geo.rowStride;
 
     // ---- role: stage s (wave-uniform) and this lane's column --------------------------------
     const int s = wave / (NB + 1) + 1;
     const int wv = wave % (NB + 1);
+    const bool halo = wv == NB;
     int x;
     bool act;
-    if (wv < NB) {
+    if (!halo) {
         x = x0 + wv * 64 + lane;
         act = x < M;
     } else {
@@ -70,127 +81,144 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
     }
     int xn = x;
     if (XMODE == XMODE_PERIODIC) xn = x < 0 ? x + M : (x >= M ? x - M : x);
-    if (!act) xn = 0;
+    if (!act) { xn = 0; x = x0; }  // inactive lanes work on a valid address and are never stored
     const int cx = x - x0 + C::HP;
-    // x edge rule flags (reference mode only); a wave without any keeps the fast paths
-    const bool ob_m = XMODE != XMODE_PERIODIC && x + 1 >= M;  // source of dx = -1 outside
-    const bool ob_p = XMODE != XMODE_PERIODIC && x - 1 < 0;   // source of dx = +1 outside
-    const bool wave_xedge = __any(act && (ob_m || ob_p));
+    // x edge rule (reference mode only): source of dx = -1 / +1 outside the domain
+    const bool ob_m = XMODE != XMODE_PERIODIC && x + 1 >= M;
+    const bool ob_p = XMODE != XMODE_PERIODIC && x - 1 < 0;
+    const bool wave_xedge = __any(ob_m || ob_p);
 
-    // per-lane element offsets inside a row of the global layout (stage 1, fast path)
+    // per-lane element offsets inside a row of the global layout (stage 1)
     int xm1 = xn + 1, xp1 = xn - 1;
     if (XMODE == XMODE_PERIODIC) { xm1 = xm1 >= M ? 0 : xm1; xp1 = xp1 < 0 ? M - 1 : xp1; }
     else { xm1 = xm1 >= M ? xn : xm1; xp1 = xp1 < 0 ? xn : xp1; }
     const int off0 = (xn >> 6) * CHUNK + (xn & 63);
     const int offm = (xm1 >> 6) * CHUNK + (xm1 & 63);
     const int offp = (xp1 >> 6) * CHUNK + (xp1 & 63);
-    const int mblk = xn >> 6;
     const unsigned mbit = xn & 63;
 
-    // ---- rows: q = this stage's row in the current iteration, qn = its storage row ----------
-    int q = y0 - (T - 1) - 2 * (s - 1);
-    int qn = q;
-    if (wrapy) { qn %= N; if (qn < 0) qn += N; }
+    // ---- rows ----------------------------------------------------------------------------------
+    const int qstart = y0 - (T - 1) - 2 * (s - 1);                        // row of iteration 0
     const int rlo = max(y0 - (T - s), qlo), rhi = min(y1 + (T - s), qhi);  // rows this stage makes
-    auto norm = [&](int r) {  // storage row of logical row r (|r - [0,N)| < N)
+    const int niter = (y1 - y0) + 3 * (T - 1);
+    auto wrap_row = [&](int r) {  // storage row of a logical row in [-N, 2N)
         if (wrapy) { r = r < 0 ? r + N : r; r = r >= N ? r - N : r; }
         return r;
     };
-    auto yedge = [&](int r) { return r - 1 < qlo || r + 1 >= qhi; };
+    auto clampr = [&](int r) { return min(max(r, rlo), rhi - 1); };
 
-    // stage 1: load the 9 pulled populations of logical row r (storage row rn) into dst
-    auto load_row = [&](int r, int rn, float* dst) {
-        if (wave_xedge || yedge(r)) {
-            if (act) pull<XMODE>(gin, geo, rn, xn >> 6, xn & 63, dst);
-        } else {
-            const ST* r0p = gin + (long long)(rn + G) * geo.rowStride;
-            const ST* rup = gin + (long long)(norm(rn - 1) + G) * geo.rowStride;
-            const ST* rdp = gin + (long long)(norm(rn + 1) + G) * geo.rowStride;
-            if (act) {
-#pragma unroll
-                for (int k = 0; k < Q; k++) {
-                    const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
-                    const ST* rb = dy == 1 ? rup : (dy == 0 ? r0p : rdp);
-                    const int off = dx == 1 ? offp : (dx == 0 ? off0 : offm);
-                    dst[k] = ld(rb + off + sl);
-                }
-            }
-        }
-    };
+    // blocked bit of (storage row rn, this lane's column)
     auto load_mask = [&](int rn) -> uint64_t {
-        return act ? mask[(long long)(rn + G) * geo.Mb + mblk] : 0ull;
+        return mask[(long long)(rn + G) * geo.Mb + (xn >> 6)];
     };
-    // stages 2..T: gather the 9 pulled populations of row r from the LDS ring of level s-1
-    auto gather = [&](int r, float* a) {
-        const float* lev = lds + (s - 2) * C::LEVF + cx;
-        const int ro0 = (r & 3) * C::ROWF, rou = ((r - 1) & 3) * C::ROWF, rod = ((r + 1) & 3) * C::ROWF;
-        if (wave_xedge || yedge(r)) {
-            const bool ob_u = r - 1 < qlo, ob_d = r + 1 >= qhi;
+
+    // stage 1: issue the 9 pulled loads of logical row r (clamped into this stage's range)
+    auto load_row = [&](auto xedge, int r, float* dst) {
+        r = clampr(r);
+        const int rn = wrap_row(r);
+        const bool ob_u = r - 1 < qlo, ob_d = r + 1 >= qhi;
+        const int rnu = ob_u ? rn : wrap_row(r - 1), rnd = ob_d ? rn : wrap_row(r + 1);
+        const ST* p0 = gin + (long long)(rn + G) * RS;
+        const ST* pu = gin + (long long)(rnu + G) * RS;
+        const ST* pd = gin + (long long)(rnd + G) * RS;
 #pragma unroll
-            for (int k = 0; k < Q; k++) {
-                const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * C::RW;
-                const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
+        for (int k = 0; k < Q; k++) {
+            const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
+            const ST* rb = dy == 1 ? pu : (dy == 0 ? p0 : pd);
+            const int off = dx == 1 ? offp : (dx == 0 ? off0 : offm);
+            const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
+            float v;
+            if (decltype(xedge)::value) {
                 const bool ox = dx == 1 ? ob_p : (dx == -1 ? ob_m : false);
-                const int src = (dy == 1 ? rou : (dy == 0 ? ro0 : rod)) - dx;
-                const float v = lev[((ox || oy) ? ro0 : src) + sl];
-                const bool inlet = (dx == 1 && ox) || (dy == 1 && oy);
-                a[k] = inlet ? geo.surr[k] : v;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < Q; k++) {
-                const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * C::RW;
-                a[k] = lev[(dy == 1 ? rou : (dy == 0 ? ro0 : rod)) - dx + sl];
-            }
-        }
-    };
-
-    // ---- prologue: prefetch rows of iterations 0 and 1 (stage 1), mask of iteration 0 ----------
-    float pa[Q], pb[Q];
-    if (s == 1) {
-        if (q >= rlo && q < rhi) load_row(q, qn, pa);
-        if (q + 1 >= rlo && q + 1 < rhi) load_row(q + 1, norm(qn + 1), pb);
-    }
-    uint64_t mw = (q >= rlo && q < rhi) ? load_mask(qn) : 0ull;
-
-    const int niter = (y1 - y0) + 3 * (T - 1);
-
-    auto body = [&](float* pre) {
-        const bool go = q >= rlo && q < rhi;  // wave-uniform
-        float a[Q];
-        if (s == 1) {
-#pragma unroll
-            for (int k = 0; k < Q; k++) a[k] = pre[k];
-            if (q + 2 >= rlo && q + 2 < rhi) load_row(q + 2, norm(norm(qn + 1) + 1), pre);
-        } else if (go && act) {
-            gather(q, a);
-        }
-        const uint64_t mcur = mw;
-        if (q + 1 >= rlo && q + 1 < rhi) mw = load_mask(norm(qn + 1));
-        if (go && act) {
-            const bool blocked = (mcur >> mbit) & 1ull;
-            reflect(a, blocked);
-            collide(a, blocked, geo.omega);
-            if (s < T) {
-                float* o = lds + (s - 1) * C::LEVF + (q & 3) * C::ROWF + cx;
-#pragma unroll
-                for (int k = 0; k < Q; k++) o[slot_of(k) * C::RW] = a[k];
+                const ST* pp = ox ? (p0 + off0) : (rb + off);
+                v = ld(pp + sl);
+                if ((dx == 1 && ox)) v = geo.surr[k];
             } else {
-                ST* o = gout + (long long)(qn + G) * geo.rowStride + off0;
-#pragma unroll
-                for (int k = 0; k < Q; k++) st_nt(o + slot_of(k) * LANES, a[k]);
+                v = ld(rb + off + sl);
             }
+            if (dy == 1) v = oy ? geo.surr[k] : v;
+            dst[k] = v;
         }
-        q += 1;
-        qn = norm(qn + 1);
+    };
+    // stages 2..T: gather the 9 pulled populations of logical row r from the ring of level s-1
+    auto gather = [&](auto xedge, int r, float* a) {
+        const float* lev = lds + (s - 2) * C::LEVF + cx;
+        const bool ob_u = r - 1 < qlo, ob_d = r + 1 >= qhi;
+        const int ro0 = (r & 3) * C::ROWF;
+        const int rou = ob_u ? ro0 : ((r - 1) & 3) * C::ROWF;
+        const int rod = ob_d ? ro0 : ((r + 1) & 3) * C::ROWF;
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * C::RW;
+            const int ro = dy == 1 ? rou : (dy == 0 ? ro0 : rod);
+            const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
+            // a source row outside the domain falls back to the own cell: own row AND own column
+            const int dxe = oy ? 0 : dx;
+            float v;
+            if (decltype(xedge)::value) {
+                const bool ox = dx == 1 ? ob_p : (dx == -1 ? ob_m : false);
+                v = lev[(ox ? ro0 : ro) - (ox ? 0 : dxe) + sl];
+                if (dx == 1 && ox) v = geo.surr[k];
+            } else {
+                v = lev[ro - dxe + sl];
+            }
+            if (dy == 1) v = oy ? geo.surr[k] : v;
+            a[k] = v;
+        }
+    };
+    auto finish_lds = [&](int r, float* a, bool blocked) {
+        reflect(a, blocked);
+        collide(a, blocked, geo.omega);
+        if (act) {
+            float* o = lds + (s - 1) * C::LEVF + (r & 3) * C::ROWF + cx;
+#pragma unroll
+            for (int k = 0; k < Q; k++) o[slot_of(k) * C::RW] = a[k];
+        }
     };
 
-    for (int i = 0; i < niter; i += 2) {
-        body(pa);
-        __syncthreads();
-        if (i + 1 < niter) body(pb);
-        __syncthreads();
-    }
+    auto run = [&](auto xedge) {
+        int q = qstart;
+        if (s == 1) {
+            float pa[Q], pb[Q];
+            load_row(xedge, q, pa);
+            load_row(xedge, q + 1, pb);
+            uint64_t mw = load_mask(wrap_row(clampr(q)));
+            auto it = [&](float* pre) {
+                float a[Q];
+#pragma unroll
+                for (int k = 0; k < Q; k++) a[k] = pre[k];
+                load_row(xedge, q + 2, pre);
+                const bool blocked = (mw >> mbit) & 1ull;
+                mw = load_mask(wrap_row(clampr(q + 1)));
+                if (act) flags[(q & (C::FROWS - 1)) * C::RW + cx] = blocked;
+                if (T > 1) finish_lds(q, a, blocked);
+                q += 1;
+                __syncthreads();
+            };
+            for (int i = 0; i < niter; i += 2) { it(pa); it(pb); }
+        } else {
+            for (int i = 0; i < niter + (niter & 1); i++) {
+                float a[Q];
+                const bool blocked = flags[(q & (C::FROWS - 1)) * C::RW + cx] != 0;
+                gather(xedge, q, a);
+                if (s < T) {
+                    finish_lds(q, a, blocked);
+                } else {
+                    reflect(a, blocked);
+                    collide(a, blocked, geo.omega);
+                    if (q >= rlo && q < rhi && act) {
+                        ST* o = gout + (long long)(wrap_row(q) + G) * RS + off0;
+#pragma unroll
+                        for (int k = 0; k < Q; k++) st_nt(o + slot_of(k) * LANES, a[k]);
+                    }
+                }
+                q += 1;
+                __syncthreads();
+            }
+        }
+    };
+    if (wave_xedge) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 template <int XMODE, int T, int NB, typename ST>
