@@ -125,8 +125,9 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
         for (int k = 0; k < Q; k++) {
             const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
             const ST* rb = dy == 1 ? pu : (dy == 0 ? p0 : pd);
-            const int off = dx == 1 ? offp : (dx == 0 ? off0 : offm);
             const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
+            // a source row outside the domain falls back to the own cell: own row AND own column
+            const int off = oy ? off0 : (dx == 1 ? offp : (dx == 0 ? off0 : offm));
             float v;
             if (decltype(xedge)::value) {
                 const bool ox = dx == 1 ? ob_p : (dx == -1 ? ob_m : false);
