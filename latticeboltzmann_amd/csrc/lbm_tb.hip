@@ -4,85 +4,86 @@
 // global memory between inner steps with a T-lane halo inside every 32-lane warp, and is racy
 // across warps.  This is a different design for CDNA4 (160 KB LDS per CU, 64-lane waves):
 //
-// A workgroup owns a strip of NB*64 columns (NB AoSoA chunks) and a chunk of Ry rows and marches
-// down the rows as a time-skewed pipeline.  In iteration i, stage s (1..T) produces time level s
-// of row  q_s(i) = y0 - (T-1) + i - 2(s-1):
+// A workgroup owns a WINDOW of W = NB*64 columns and a chunk of Ry rows and marches down the rows
+// as a time-skewed pipeline.  In iteration i, stage s (1..T) produces time level s of row
+// q_s(i) = y0 - (T-1) + i - 2(s-1), for ALL W columns of the window:
 //     stage 1     pulls level 0 straight from HBM (the same coalesced 768-byte pieces as the T=1
 //                 kernel), software-prefetched two iterations ahead in registers;
 //     stage 2..T  pull from a 4-row LDS ring of level s-1;
-//     stage s<T   writes its row into the LDS ring of level s, stage T stores to HBM (full lines).
-// Waves: per stage NB "main" waves (one per 64-column block) and, for s < T, one "halo" wave
-// whose first 2(T-s) lanes recompute the T-s columns on either side of the strip that the next
-// level needs.  All waves of a stage share the row (wave-uniform) and differ only in a per-lane
-// column, so they run the same code.  All stages run concurrently; one barrier per iteration
-// separates an iteration's ring writes from the next iteration's reads (skew 2 per stage =>
-// ring depth 4).  Per T updates the strip's cells are read once and written once: HBM bytes per
-// cell-update = 72/T (+ halo columns and 3(T-1) warm-up rows per chunk).  Every cell goes through
-// the same pull/reflect/collide device functions as the T=1 kernel, so results are bit-identical
-// to T single updates.
+//     stage s<T   writes its row into the LDS ring of level s, stage T stores to HBM.
+// One wave per (stage, 64-column block): T*NB waves, all running the same code.  Level 1 is
+// right in every window column; each further level loses one column at either window edge
+// (its neighbour lies outside the window), so only the inner W - 2*MARG columns (MARG = 8 >= T-1)
+// are stored: windows of neighbouring workgroups overlap by 16 columns (halo recompute, 6 %).
+// Output strips are 16 columns (64 bytes per population) aligned.  All stages run concurrently;
+// one barrier per iteration separates an iteration's ring writes from the next iteration's reads
+// (skew 2 per stage => ring depth 4).  Per T updates the cells are read once (1.07x with the
+// overlap, mostly L2 hits) and written once: HBM bytes per cell-update = 72/T (+ 3(T-1) warm-up
+// rows per chunk).  Every cell goes through the same pull/reflect/collide device functions as
+// the T=1 kernel, so results are bit-identical to T single updates.
+//
+// All loads in the row loops are unconditional and straight-line (rows outside a stage's range are
+// clamped to a valid row instead of skipped), so that hipcc can use counted s_waitcnt vmcnt(N) and
+// the stage-1 prefetch really stays in flight across two iterations and barriers.  Only stage 1
+// touches the bit-packed mask; it hands each cell's blocked flag to the later stages through LDS.
 #include <type_traits>
 
 #include "lbm_internal.h"
 
 namespace lbm {
 
+constexpr int TB_MARG = 8;  // window columns on either side that are computed but not stored
+
 template <int T, int NB>
 struct TB {
-    static constexpr int SW = NB * 64;           // strip width
-    static constexpr int HP = T - 1;             // halo columns kept per side
-    static constexpr int RW = SW + 2 * HP;       // floats per slot row
+    static_assert(T - 1 <= TB_MARG, "margin too small for this depth");
+    static constexpr int W = NB * 64;            // window width (columns computed per stage)
+    static constexpr int SW = W - 2 * TB_MARG;   // strip width (columns stored)
+    static constexpr int RW = W + 2;             // floats per slot row (+1 pad either side)
     static constexpr int ROWF = Q * RW;          // floats per ring row
     static constexpr int LEVF = 4 * ROWF;        // floats per level (ring of 4 rows)
     static constexpr int LDSF = (T - 1) * LEVF;
-    static constexpr int NW = T * (NB + 1) - 1;  // waves: NB main per stage + a halo wave for s < T
+    static constexpr int NW = T * NB;            // waves
     static constexpr int FROWS = 16;             // ring depth of the blocked-flag rows (> 2(T-1)+1)
 };
 
-// All loads in the row loops are unconditional and straight-line (rows outside a stage's range
-// are clamped to a valid row instead of skipped), so that hipcc can use counted s_waitcnt vmcnt(N)
-// and the stage-1 prefetch really stays in flight across two iterations and barriers.
 template <int XMODE, int T, int NB, typename ST>
 __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
     const ST* __restrict__ gin, ST* __restrict__ gout, const uint64_t* __restrict__ mask, Geom geo,
     int row0, int nrows, int Ry, int nstrips) {
     using C = TB<T, NB>;
     __shared__ float lds[C::LDSF];
-    // blocked flags of level-1 cells, written by stage 1 and read by the later stages, so that
-    // only stage 1 loads the bit-packed mask from global memory
     __shared__ uint8_t flags[C::FROWS * C::RW];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
     const int strip = wg % nstrips, chunk = wg / nstrips;
-    const int x0 = strip * C::SW;
+    const int xo = strip * C::SW;  // first stored column
     const int y0 = row0 + chunk * Ry;
     const int y1 = min(y0 + Ry, row0 + nrows);
     const int N = geo.N, M = geo.M, G = geo.G;
-    const int Wv = min(C::SW, M - x0);
     const bool wrapy = geo.top == YEDGE_WRAP;  // top and bottom wrap together
     const int qlo = geo.top == YEDGE_DOMAIN ? 0 : -(1 << 28);  // rows that exist
     const int qhi = geo.bot == YEDGE_DOMAIN ? N : (1 << 28);
     const long long RS = geo.rowStride;
+    const float omega = geo.omega;
+    const float su0 = geo.surr[0], su1 = geo.surr[1], su2 = geo.surr[2], su3 = geo.surr[3],
+                su4 = geo.surr[4], su5 = geo.surr[5], su6 = geo.surr[6], su7 = geo.surr[7],
+                su8 = geo.surr[8];
+    auto surr = [&](int k) {  // k is a compile-time constant after unrolling
+        return k == 0 ? su0 : k == 1 ? su1 : k == 2 ? su2 : k == 3 ? su3 : k == 4 ? su4
+             : k == 5 ? su5 : k == 6 ? su6 : k == 7 ? su7 : su8;
+    };
 
     // ---- role: stage s (wave-uniform) and this lane's column --------------------------------
-    const int s = wave / (NB + 1) + 1;
-    const int wv = wave % (NB + 1);
-    const bool halo = wv == NB;
-    int x;
-    bool act;
-    if (!halo) {
-        x = x0 + wv * 64 + lane;
-        act = x < M;
-    } else {
-        const int n = T - s;
-        x = lane < n ? x0 - 1 - lane : x0 + Wv + (lane - n);
-        act = lane < 2 * n;
-        if (XMODE != XMODE_PERIODIC) act = act && x >= 0 && x < M;
-    }
-    int xn = x;
-    if (XMODE == XMODE_PERIODIC) xn = x < 0 ? x + M : (x >= M ? x - M : x);
-    if (!act) { xn = 0; x = x0; }  // inactive lanes work on a valid address and are never stored
-    const int cx = x - x0 + C::HP;
+    const int s = wave / NB + 1;
+    const int j = wave % NB;
+    const int cx = 1 + j * 64 + lane;              // column index inside a ring row
+    const int x = xo - TB_MARG + j * 64 + lane;    // logical column
+    int xn;                                        // storage column
+    if (XMODE == XMODE_PERIODIC) { xn = x % M; if (xn < 0) xn += M; }
+    else xn = min(max(x, 0), M - 1);               // outside the domain: a valid address, unused
+    const bool stored = x >= xo && x < xo + C::SW && x < M;
     // x edge rule (reference mode only): source of dx = -1 / +1 outside the domain
     const bool ob_m = XMODE != XMODE_PERIODIC && x + 1 >= M;
     const bool ob_p = XMODE != XMODE_PERIODIC && x - 1 < 0;
@@ -106,8 +107,6 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
         return r;
     };
     auto clampr = [&](int r) { return min(max(r, rlo), rhi - 1); };
-
-    // blocked bit of (storage row rn, this lane's column)
     auto load_mask = [&](int rn) -> uint64_t {
         return mask[(long long)(rn + G) * geo.Mb + (xn >> 6)];
     };
@@ -133,11 +132,11 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
                 const bool ox = dx == 1 ? ob_p : (dx == -1 ? ob_m : false);
                 const ST* pp = ox ? (p0 + off0) : (rb + off);
                 v = ld(pp + sl);
-                if ((dx == 1 && ox)) v = geo.surr[k];
+                if ((dx == 1 && ox)) v = surr(k);
             } else {
                 v = ld(rb + off + sl);
             }
-            if (dy == 1) v = oy ? geo.surr[k] : v;
+            if (dy == 1) v = oy ? surr(k) : v;
             dst[k] = v;
         }
     };
@@ -153,28 +152,23 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
             const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * C::RW;
             const int ro = dy == 1 ? rou : (dy == 0 ? ro0 : rod);
             const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
-            // a source row outside the domain falls back to the own cell: own row AND own column
-            const int dxe = oy ? 0 : dx;
+            const int dxe = oy ? 0 : dx;  // own-cell fallback: own row AND own column
             float v;
             if (decltype(xedge)::value) {
                 const bool ox = dx == 1 ? ob_p : (dx == -1 ? ob_m : false);
                 v = lev[(ox ? ro0 : ro) - (ox ? 0 : dxe) + sl];
-                if (dx == 1 && ox) v = geo.surr[k];
+                if (dx == 1 && ox) v = surr(k);
             } else {
                 v = lev[ro - dxe + sl];
             }
-            if (dy == 1) v = oy ? geo.surr[k] : v;
+            if (dy == 1) v = oy ? surr(k) : v;
             a[k] = v;
         }
     };
-    auto finish_lds = [&](int r, float* a, bool blocked) {
-        reflect(a, blocked);
-        collide(a, blocked, geo.omega);
-        if (act) {
-            float* o = lds + (s - 1) * C::LEVF + (r & 3) * C::ROWF + cx;
+    auto to_lds = [&](int r, const float* a) {
+        float* o = lds + (s - 1) * C::LEVF + (r & 3) * C::ROWF + cx;
 #pragma unroll
-            for (int k = 0; k < Q; k++) o[slot_of(k) * C::RW] = a[k];
-        }
+        for (int k = 0; k < Q; k++) o[slot_of(k) * C::RW] = a[k];
     };
 
     auto run = [&](auto xedge) {
@@ -191,8 +185,10 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
                 load_row(xedge, q + 2, pre);
                 const bool blocked = (mw >> mbit) & 1ull;
                 mw = load_mask(wrap_row(clampr(q + 1)));
-                if (act) flags[(q & (C::FROWS - 1)) * C::RW + cx] = blocked;
-                if (T > 1) finish_lds(q, a, blocked);
+                flags[(q & (C::FROWS - 1)) * C::RW + cx] = blocked;
+                reflect(a, blocked);
+                collide(a, blocked, omega);
+                to_lds(q, a);
                 q += 1;
                 __syncthreads();
             };
@@ -202,16 +198,14 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
                 float a[Q];
                 const bool blocked = flags[(q & (C::FROWS - 1)) * C::RW + cx] != 0;
                 gather(xedge, q, a);
+                reflect(a, blocked);
+                collide(a, blocked, omega);
                 if (s < T) {
-                    finish_lds(q, a, blocked);
-                } else {
-                    reflect(a, blocked);
-                    collide(a, blocked, geo.omega);
-                    if (q >= rlo && q < rhi && act) {
-                        ST* o = gout + (long long)(wrap_row(q) + G) * RS + off0;
+                    to_lds(q, a);
+                } else if (q >= rlo && q < rhi && stored) {
+                    ST* o = gout + (long long)(wrap_row(q) + G) * RS + off0;
 #pragma unroll
-                        for (int k = 0; k < Q; k++) st_nt(o + slot_of(k) * LANES, a[k]);
-                    }
+                    for (int k = 0; k < Q; k++) st_nt(o + slot_of(k) * LANES, a[k]);
                 }
                 q += 1;
                 __syncthreads();
@@ -253,7 +247,7 @@ hipError_t launch_step_tb(const void* gin, void* gout, const uint64_t* mask, con
     switch (T) {
         case 2: launch_tb_T<2, 4>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
         case 3: launch_tb_T<3, 4>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
-        case 4: launch_tb_T<4, 3>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
+        case 4: launch_tb_T<4, 4>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
