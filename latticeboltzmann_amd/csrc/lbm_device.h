@@ -109,12 +109,16 @@ __device__ __forceinline__ void pull(const T* __restrict__ g, const Geom& geo, i
 }
 
 // --- reflect (latticeboltzmann.py:122-123): k <-> 8-k at blocked cells ------------------------
+// Obstacles are sparse (< 1 % of the reference's scenes): a wave without a blocked lane skips
+// the eight selects.
 __device__ __forceinline__ void reflect(float t[Q], bool blocked) {
+    if (__any(blocked)) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float a = t[k], b = t[8 - k];
-        t[k] = blocked ? b : a;
-        t[8 - k] = blocked ? a : b;
+        for (int k = 0; k < 4; k++) {
+            float a = t[k], b = t[8 - k];
+            t[k] = blocked ? b : a;
+            t[8 - k] = blocked ? a : b;
+        }
     }
 }
 
@@ -132,8 +136,15 @@ __device__ __forceinline__ void moments(const float a[Q], float& p, float& u0, f
     m0 = m0 + a[2]; m0 = m0 - a[3]; m0 = m0 + a[5]; m0 = m0 - a[6]; m0 = m0 + a[8];
     float m1 = 0.0f - a[0];
     m1 = m1 - a[1]; m1 = m1 - a[2]; m1 = m1 + a[6]; m1 = m1 + a[7]; m1 = m1 + a[8];
-    u0 = nan_to_num(m0 / p);
-    u1 = nan_to_num(m1 / p);
+    u0 = m0 / p;
+    u1 = m1 / p;
+    // np.nan_to_num only acts on non-finite values (p == 0 or a blown-up cell): rare, so the
+    // fix-up is a wave-uniform branch instead of ten selects per cell.
+    const float inf = __builtin_inff();
+    if (__any(!(__builtin_fabsf(u0) < inf) || !(__builtin_fabsf(u1) < inf))) {
+        u0 = nan_to_num(u0);
+        u1 = nan_to_num(u1);
+    }
 }
 
 // --- equilibrium (latticeboltzmann.py:87-89) ---------------------------------------------------
@@ -169,6 +180,69 @@ __device__ __forceinline__ void collide(float a[Q], bool blocked, float omega_fr
 #pragma unroll
     for (int k = 0; k < Q; k++) {
         float v = a[k] - eq[k];
+        v = v * om;
+        a[k] = v + eq[k];
+    }
+}
+
+// --- two cells per lane, packed fp32 ------------------------------------------------------------
+// gfx950 issues v_pk_add_f32 / v_pk_mul_f32 (two fp32 results per lane) at nearly the rate of the
+// scalar forms (tools/valu_rate.hip), so the VALU-bound temporal-blocking kernel gives every lane
+// two cells and runs collide on float2 vectors.  Each component goes through exactly the same
+// IEEE operations in the same order as the scalar functions above: bit-identical results.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void reflect2(f2 t[Q], bool b0, bool b1) {
+    if (__any(b0 || b1)) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const f2 a = t[k], b = t[8 - k];
+            t[k] = f2{b0 ? b.x : a.x, b1 ? b.y : a.y};
+            t[8 - k] = f2{b0 ? a.x : b.x, b1 ? a.y : b.y};
+        }
+    }
+}
+
+__device__ __forceinline__ void moments2(const f2 a[Q], f2& p, f2& u0, f2& u1) {
+    p = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + a[8];
+    f2 m0 = 0.0f - a[0];
+    m0 = m0 + a[2]; m0 = m0 - a[3]; m0 = m0 + a[5]; m0 = m0 - a[6]; m0 = m0 + a[8];
+    f2 m1 = 0.0f - a[0];
+    m1 = m1 - a[1]; m1 = m1 - a[2]; m1 = m1 + a[6]; m1 = m1 + a[7]; m1 = m1 + a[8];
+    u0 = m0 / p;  // two IEEE divisions each
+    u1 = m1 / p;
+    const float inf = __builtin_inff();
+    if (__any(!(__builtin_fabsf(u0.x) < inf) || !(__builtin_fabsf(u0.y) < inf) ||
+              !(__builtin_fabsf(u1.x) < inf) || !(__builtin_fabsf(u1.y) < inf))) {
+        u0 = f2{nan_to_num(u0.x), nan_to_num(u0.y)};
+        u1 = f2{nan_to_num(u1.x), nan_to_num(u1.y)};
+    }
+}
+
+__device__ __forceinline__ void equilibrium2(f2 u0, f2 u1, f2 p, f2 eq[Q]) {
+    const float W_CORNER = 1.0f / 36, W_AXIS = 1.0f / 9, W_REST = 4.0f / 9;
+    const f2 c = 1.5f * (u0 * u0 + u1 * u1);
+    const f2 pc = p * W_CORNER, pa = p * W_AXIS, pr = p * W_REST;
+    const f2 sp = u0 + u1, sm = u0 - u1;
+    { const f2 q = 4.5f * (sp * sp), h = 3.0f * sp;
+      eq[8] = pc * (((1.0f + h) + q) - c); eq[0] = pc * (((1.0f - h) + q) - c); }
+    { const f2 q = 4.5f * (u1 * u1), h = 3.0f * u1;
+      eq[7] = pa * (((1.0f + h) + q) - c); eq[1] = pa * (((1.0f - h) + q) - c); }
+    { const f2 q = 4.5f * (sm * sm), h = 3.0f * sm;
+      eq[2] = pc * (((1.0f + h) + q) - c); eq[6] = pc * (((1.0f - h) + q) - c); }
+    { const f2 q = 4.5f * (u0 * u0), h = 3.0f * u0;
+      eq[5] = pa * (((1.0f + h) + q) - c); eq[3] = pa * (((1.0f - h) + q) - c); }
+    eq[4] = pr * (1.0f - c);
+}
+
+__device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, float omega_free) {
+    f2 p, u0, u1, eq[Q];
+    moments2(a, p, u0, u1);
+    equilibrium2(u0, u1, p, eq);
+    const f2 om = f2{b0 ? 1.0f : omega_free, b1 ? 1.0f : omega_free};
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        f2 v = a[k] - eq[k];
         v = v * om;
         a[k] = v + eq[k];
     }

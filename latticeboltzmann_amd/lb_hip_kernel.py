@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblbm_hip.so")
+LIB_PATH = os.environ.get("LBM_HIP_LIB", os.path.join(_HERE, "liblbm_hip.so"))  # env: dev experiments
 
 BOUNDARY_REFERENCE, BOUNDARY_PERIODIC = 0, 1
 YEDGE_DOMAIN, YEDGE_SEAM = 0, 1

@@ -91,3 +91,34 @@ def test_numpy_oracle_agrees_too():
     onp.run(ref, blocked, 100)
     _compare(s, ref)
     s.close()
+
+
+def test_zero_density_and_non_finite_cells():
+    """np.nan_to_num semantics (latticeboltzmann.py:183): rho == 0 gives u = 0 (0/0 -> nan -> 0),
+    and +-inf becomes +-FLT_MAX.  Scene: the .jl draft's start (latticeboltzmann.jl:94: zero
+    populations inside obstacles) plus a few cells with zero density but non-zero momentum."""
+    N, M = 40, 130
+    blocked = onp.blocked_cylinder(N, M)
+    surr = onp.ambient()
+    cells = onp.initial_cells(blocked, surr)
+    cells[blocked] = 0
+    cells[5, 7] = [1, 0, 0, 0, 0, 0, 0, 0, -1]
+    cells[30, 100] = [0, 2, 0, 0, 0, 0, 0, -2, 0]
+    for T in (1, 3):
+        from latticeboltzmann_amd.lb_hip_kernel import Solver
+        s = Solver(N, M, 0.5, inner_timesteps=T, boundary="reference")
+        s.set_surroundings(surr)
+        s.upload_blocked(blocked)
+        s.upload_cells(cells)
+        ref = cells.copy()
+        with np.errstate(all="ignore"):
+            for _ in range(2):
+                s.fused_collide_stream(1)
+                oc.run(ref, blocked, T, 0.5, surr)
+                got = s.read_cells()
+                assert np.array_equal(got, ref, equal_nan=True)
+        refn = cells.copy()
+        with np.errstate(all="ignore"):
+            onp.run(refn, blocked, 2 * T, 0.5)
+        assert np.array_equal(refn, ref, equal_nan=True)  # the C twin follows numpy here too
+        s.close()
