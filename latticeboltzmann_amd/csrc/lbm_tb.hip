@@ -30,8 +30,17 @@
 
 #include "lbm_internal.h"
 
-#ifndef LBM_TB_PF
-#define LBM_TB_PF 2
+#ifndef LBM_TB_NB2
+#define LBM_TB_NB2 4
+#define LBM_TB_CPL2 1
+#endif
+#ifndef LBM_TB_NB3
+#define LBM_TB_NB3 4
+#define LBM_TB_CPL3 1
+#endif
+#ifndef LBM_TB_NB4
+#define LBM_TB_NB4 4
+#define LBM_TB_CPL4 2
 #endif
 #ifndef LBM_TB_MARG
 #define LBM_TB_MARG 8
@@ -42,33 +51,52 @@
 
 namespace lbm {
 
-constexpr int TB_PF = LBM_TB_PF;  // stage-1 rows in flight
 constexpr int TB_MARG = LBM_TB_MARG;  // window columns on either side that are computed but not stored
 
-template <int T, int NB>
+template <int T, int NB, int CPL>
 struct TB {
     static_assert(T - 1 <= TB_MARG, "margin too small for this depth");
-    static_assert(NB % 2 == 0, "a lane owns two 64-column blocks");
+    static_assert(NB % CPL == 0, "a lane owns CPL 64-column blocks");
     static constexpr int W = NB * 64;            // window width (columns computed per stage)
     static constexpr int SW = W - 2 * TB_MARG;   // strip width (columns stored)
     static constexpr int RW = W + 2;             // floats per slot row (+1 pad either side)
-    static constexpr int ROWF = Q * RW;          // floats per ring row
-    static constexpr int LEVF = 4 * ROWF;        // floats per level (ring of 4 rows)
-    static constexpr int LDSF = (T - 1) * LEVF;
-    static constexpr int NW = T * NB / 2;        // waves: one per (stage, pair of blocks)
-    static constexpr int FROWS = 16;             // ring depth of the blocked-flag rows (> 2(T-1)+1)
+    static constexpr int ROWB = (37 * RW + 15) / 16 * 16;  // ring row: 9 fp32 slots + a flag byte row, 16-B aligned
+    static constexpr int LEVB = 4 * ROWB;        // bytes per level (ring of 4 rows)
+    static constexpr int LDSB = (T - 1) * LEVB;
+    static constexpr int NW = T * NB / CPL;      // waves: one per (stage, CPL blocks)
 };
 
-// Every lane owns TWO cells of its stage's row, 64 columns apart (blocks 2j and 2j+1 of the
-// window), held as the .x / .y halves of float2 registers, so that collide runs on packed fp32
-// instructions (the kernel is VALU-bound, not HBM-bound).
-template <int XMODE, int T, int NB, int PF, typename ST>
-__global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
+// value type of a lane: one cell (float) or two cells 64 columns apart (packed float2)
+template <int CPL> struct LaneV;
+template <> struct LaneV<1> {
+    using V = float;
+    static __device__ __forceinline__ V make(const float* v) { return v[0]; }
+    static __device__ __forceinline__ float get(V v, int) { return v; }
+};
+template <> struct LaneV<2> {
+    using V = f2;
+    static __device__ __forceinline__ V make(const float* v) { return f2{v[0], v[1]}; }
+    static __device__ __forceinline__ float get(V v, int c) { return c == 0 ? v.x : v.y; }
+};
+__device__ __forceinline__ void reflect_v(float* a, const bool* b) { reflect(a, b[0]); }
+__device__ __forceinline__ void reflect_v(f2* a, const bool* b) { reflect2(a, b[0], b[1]); }
+__device__ __forceinline__ void collide_v(float* a, const bool* b, float om) { collide(a, b[0], om); }
+__device__ __forceinline__ void collide_v(f2* a, const bool* b, float om) { collide2(a, b[0], b[1], om); }
+
+// Ring slots are addressed by ITERATION, not by row: in iteration i a stage writes its row into
+// slot i & 3 of its level, and the next stage (two rows behind) finds rows q-1, q, q+1 in slots
+// (i+1) & 3, (i+2) & 3, (i+3) & 3.  The row loop is unrolled by four, so every LDS address is a
+// per-lane base plus a compile-time offset.  A cell's blocked flag travels through the rings as
+// a tenth, one-byte "slot": only stage 1 reads the bit-packed mask.
+template <int XMODE, int T, int NB, int CPL, typename ST>
+__global__ __launch_bounds__((TB<T, NB, CPL>::NW * 64)) void step_tb_kernel(
     const ST* __restrict__ gin, ST* __restrict__ gout, const uint64_t* __restrict__ mask, Geom geo,
     int row0, int nrows, int Ry, int nstrips) {
-    using C = TB<T, NB>;
-    __shared__ float lds[C::LDSF];
-    __shared__ uint8_t flags[C::FROWS * C::RW];
+    using C = TB<T, NB, CPL>;
+    using L = LaneV<CPL>;
+    using V = typename L::V;
+    constexpr int PF = 2;  // stage-1 rows in flight
+    __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDSB];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -90,52 +118,60 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
              : k == 5 ? su5 : k == 6 ? su6 : k == 7 ? su7 : su8;
     };
 
-    // ---- role: stage s (wave-uniform) and this lane's two columns (c = 0, 1) --------------------
-    const int s = wave / (NB / 2) + 1;
-    const int j = wave % (NB / 2);
-    const int cx = 1 + j * 128 + lane;  // ring-row index of cell 0; cell 1 is 64 further
-    int xs[2], off0[2], offm[2], offp[2];
-    unsigned mbit[2];
-    int mblk[2];
-    bool stored[2], ob_m[2], ob_p[2];
+    // ---- role: stage s (wave-uniform) and this lane's CPL columns ------------------------------
+    constexpr int WPS = NB / CPL;  // waves per stage
+    const int s = wave / WPS + 1;
+    const int j = wave % WPS;
+    const int cx = 1 + j * (64 * CPL) + lane;  // ring-row index of cell 0; cell c is 64*c further
+    int off0[CPL], offm[CPL], offp[CPL], mblk[CPL];
+    unsigned mbit[CPL];
+    bool stored[CPL], ob_m[CPL], ob_p[CPL];
+    bool any_xedge = false;
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int x = xo - TB_MARG + j * 128 + c * 64 + lane;  // logical column
-        int xn;                                                // storage column
+    for (int c = 0; c < CPL; c++) {
+        const int x = xo - TB_MARG + j * (64 * CPL) + c * 64 + lane;  // logical column
+        int xn;                                                       // storage column
         if (XMODE == XMODE_PERIODIC) { xn = x % M; if (xn < 0) xn += M; }
         else xn = min(max(x, 0), M - 1);  // outside the domain: a valid address, never stored
         stored[c] = x >= xo && x < xo + C::SW && x < M;
         // x edge rule (reference mode only): source of dx = -1 / +1 outside the domain
         ob_m[c] = XMODE != XMODE_PERIODIC && x + 1 >= M;
         ob_p[c] = XMODE != XMODE_PERIODIC && x - 1 < 0;
+        any_xedge = any_xedge || ob_m[c] || ob_p[c];
         int xm1 = xn + 1, xp1 = xn - 1;
         if (XMODE == XMODE_PERIODIC) { xm1 = xm1 >= M ? 0 : xm1; xp1 = xp1 < 0 ? M - 1 : xp1; }
         else { xm1 = xm1 >= M ? xn : xm1; xp1 = xp1 < 0 ? xn : xp1; }
-        xs[c] = x;
         off0[c] = (xn >> 6) * CHUNK + (xn & 63);
         offm[c] = (xm1 >> 6) * CHUNK + (xm1 & 63);
         offp[c] = (xp1 >> 6) * CHUNK + (xp1 & 63);
         mblk[c] = xn >> 6;
         mbit[c] = xn & 63;
     }
-    const bool wave_xedge = __any(ob_m[0] || ob_p[0] || ob_m[1] || ob_p[1]);
+    const bool wave_xedge = __any(any_xedge);
 
     // ---- rows ----------------------------------------------------------------------------------
     const int qstart = y0 - (T - 1) - 2 * (s - 1);                        // row of iteration 0
     const int rlo = max(y0 - (T - s), qlo), rhi = min(y1 + (T - s), qhi);  // rows this stage makes
     const int niter = (y1 - y0) + 3 * (T - 1);
-    const int nit = (niter + PF - 1) / PF * PF;  // every wave runs the same number of barriers
+    const int nit = (niter + 3) & ~3;  // unrolled by 4; every wave runs the same number of barriers
     auto wrap_row = [&](int r) {  // storage row of a logical row in [-N, 2N)
         if (wrapy) { r = r < 0 ? r + N : r; r = r >= N ? r - N : r; }
         return r;
     };
     auto clampr = [&](int r) { return min(max(r, rlo), rhi - 1); };
 
-    // stage 1: issue the 2 x 9 pulled loads of logical row r (clamped into this stage's range) and
-    // the two mask words.  Pure loads from always-valid addresses (a source outside the domain is
+    // LDS views.  Level l (1..T-1) lives at lds + (l-1)*LEVB; ring slot t at + t*ROWB; inside a
+    // slot: population slot k at float index k*RW + column, flags at byte 36*RW + column.
+    unsigned char* const wr_base = lds + (s - 1) * C::LEVB + cx * 4;  // this stage's level (s < T)
+    const unsigned char* const rd_base = lds + (s - 2) * C::LEVB + cx * 4;  // level s-1 (s > 1)
+    unsigned char* const wr_flag = lds + (s - 1) * C::LEVB + 36 * C::RW + cx;
+    const unsigned char* const rd_flag = lds + (s - 2) * C::LEVB + 36 * C::RW + cx;
+
+    // stage 1: issue the CPL x 9 pulled loads of logical row r (clamped into this stage's range)
+    // and the mask words.  Pure loads from always-valid addresses (a source outside the domain is
     // replaced by the own cell); the inlet rule is applied when the row is consumed (inlet_fix),
     // so that no load sits behind a branch and the vmcnt bookkeeping stays exact.
-    auto load_row = [&](auto xedge, int r, f2* dst, uint64_t* mw) {
+    auto load_row = [&](auto xedge, int r, V* dst, uint64_t* mw) {
         r = clampr(r);
         const int rn = wrap_row(r);
         const bool ob_u = r - 1 < qlo, ob_d = r + 1 >= qhi;
@@ -147,10 +183,10 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
         for (int k = 0; k < Q; k++) {
             const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
             const ST* rb = dy == 1 ? pu : (dy == 0 ? p0 : pd);
-            const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
-            float v[2];
+            const bool oy = XMODE != XMODE_PERIODIC && (dy == 1 ? ob_u : (dy == -1 ? ob_d : false));
+            float v[CPL];
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < CPL; c++) {
                 // a source row outside the domain falls back to the own cell: own row AND column
                 const int off = oy ? off0[c] : (dx == 1 ? offp[c] : (dx == 0 ? off0[c] : offm[c]));
                 if (decltype(xedge)::value) {
@@ -161,58 +197,66 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
                     v[c] = ld(rb + off + sl);
                 }
             }
-            dst[k] = f2{v[0], v[1]};
+            dst[k] = L::make(v);
         }
         const uint64_t* mrow = mask + (long long)(rn + G) * geo.Mb;
-        mw[0] = mrow[mblk[0]];
-        mw[1] = mrow[mblk[1]];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) mw[c] = mrow[mblk[c]];
     };
-    auto inlet_fix = [&](auto xedge, int r, f2* a) {
+    auto inlet_fix = [&](auto xedge, int r, V* a) {
         if (XMODE == XMODE_PERIODIC) return;  // no domain edge in x, and y wraps or is a seam
         const bool ob_u = r - 1 < qlo;
 #pragma unroll
         for (int k = 0; k < Q; k++) {
             const int dy = dy_of(k), dx = dx_of(k);
-            if (decltype(xedge)::value && dx == 1)
-                a[k] = f2{ob_p[0] ? surr(k) : a[k].x, ob_p[1] ? surr(k) : a[k].y};
-            if (dy == 1) a[k] = ob_u ? f2{surr(k), surr(k)} : a[k];
-        }
-    };
-    // stages 2..T: gather the pulled populations of logical row r from the ring of level s-1
-    auto gather = [&](auto xedge, int r, f2* a) {
-        const float* lev = lds + (s - 2) * C::LEVF + cx;
-        const bool ob_u = r - 1 < qlo, ob_d = r + 1 >= qhi;
-        const int ro0 = (r & 3) * C::ROWF;
-        const int rou = ob_u ? ro0 : ((r - 1) & 3) * C::ROWF;
-        const int rod = ob_d ? ro0 : ((r + 1) & 3) * C::ROWF;
+            float v[CPL];
 #pragma unroll
-        for (int k = 0; k < Q; k++) {
-            const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * C::RW;
-            const int ro = dy == 1 ? rou : (dy == 0 ? ro0 : rod);
-            const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
-            const int dxe = oy ? 0 : dx;  // own-cell fallback: own row AND own column
-            float v[2];
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                if (decltype(xedge)::value) {
-                    const bool ox = dx == 1 ? ob_p[c] : (dx == -1 ? ob_m[c] : false);
-                    v[c] = lev[(ox ? ro0 : ro) - (ox ? 0 : dxe) + sl + 64 * c];
-                    if (dx == 1 && ox) v[c] = surr(k);
-                } else {
-                    v[c] = lev[ro - dxe + sl + 64 * c];
-                }
-                if (XMODE != XMODE_PERIODIC && dy == 1) v[c] = oy ? surr(k) : v[c];
+            for (int c = 0; c < CPL; c++) {
+                v[c] = L::get(a[k], c);
+                if (decltype(xedge)::value && dx == 1) v[c] = ob_p[c] ? surr(k) : v[c];
+                if (dy == 1) v[c] = ob_u ? surr(k) : v[c];
             }
-            a[k] = f2{v[0], v[1]};
+            a[k] = L::make(v);
         }
     };
-    auto to_lds = [&](int r, const f2* a) {
-        float* o = lds + (s - 1) * C::LEVF + (r & 3) * C::ROWF + cx;
+    // stages 2..T, iteration phase PH = i & 3: gather the pulled populations of row r and the
+    // blocked flags from the ring of level s-1
+    auto gather = [&](auto xedge, auto ph, int r, V* a, bool* blocked) {
+        constexpr int PH = decltype(ph)::value;
+        constexpr int SU = ((PH + 1) & 3) * C::ROWB, S0 = ((PH + 2) & 3) * C::ROWB,
+                      SD = ((PH + 3) & 3) * C::ROWB;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) blocked[c] = rd_flag[S0 + 64 * c] != 0;
+        const bool ob_u = XMODE != XMODE_PERIODIC && r - 1 < qlo;
+        const bool ob_d = XMODE != XMODE_PERIODIC && r + 1 >= qhi;
 #pragma unroll
         for (int k = 0; k < Q; k++) {
-            o[slot_of(k) * C::RW] = a[k].x;
-            o[slot_of(k) * C::RW + 64] = a[k].y;
+            const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * C::RW * 4;
+            const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
+            const int ro = dy == 1 ? SU : (dy == 0 ? S0 : SD);
+            float v[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const bool ox = decltype(xedge)::value && (dx == 1 ? ob_p[c] : (dx == -1 ? ob_m[c] : false));
+                // own-cell fallback (own row AND own column) when the source is outside the domain
+                const int o = (oy || ox) ? S0 : ro - 4 * dx;
+                v[c] = *reinterpret_cast<const float*>(rd_base + o + sl + 256 * c);
+                if (decltype(xedge)::value && dx == 1) v[c] = ob_p[c] ? surr(k) : v[c];
+                if (XMODE != XMODE_PERIODIC && dy == 1) v[c] = ob_u ? surr(k) : v[c];
+            }
+            a[k] = L::make(v);
         }
+    };
+    auto to_lds = [&](auto ph, const V* a, const bool* blocked) {
+        constexpr int SWR = decltype(ph)::value * C::ROWB;
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+#pragma unroll
+            for (int c = 0; c < CPL; c++)
+                *reinterpret_cast<float*>(wr_base + SWR + slot_of(k) * C::RW * 4 + 256 * c) = L::get(a[k], c);
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; c++) wr_flag[SWR + 64 * c] = blocked[c];
     };
 
     auto run = [&](auto xedge) {
@@ -220,53 +264,65 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
         if (s == 1) {
             // PF rows in flight: row q+PF is requested while row q is consumed; the mask words
             // travel with their row (vmcnt retires in order)
-            f2 pre[PF][Q];
-            uint64_t pmw[PF][2];
+            V pre[PF][Q];
+            uint64_t pmw[PF][CPL];
 #pragma unroll
             for (int d = 0; d < PF; d++) load_row(xedge, q + d, pre[d], pmw[d]);
-            auto it = [&](f2* pr, uint64_t* mw) {
-                f2 a[Q];
+            auto it = [&](auto ph, V* pr, uint64_t* mw) {
+                V a[Q];
+                bool blocked[CPL];
 #pragma unroll
                 for (int k = 0; k < Q; k++) a[k] = pr[k];
                 inlet_fix(xedge, clampr(q), a);
-                const bool b0 = (mw[0] >> mbit[0]) & 1ull, b1 = (mw[1] >> mbit[1]) & 1ull;
+#pragma unroll
+                for (int c = 0; c < CPL; c++) blocked[c] = (mw[c] >> mbit[c]) & 1ull;
                 load_row(xedge, q + PF, pr, mw);
-                uint8_t* fl = flags + (q & (C::FROWS - 1)) * C::RW + cx;
-                fl[0] = b0;
-                fl[64] = b1;
-                reflect2(a, b0, b1);
-                collide2(a, b0, b1, omega);
-                to_lds(q, a);
+                reflect_v(a, blocked);
+                collide_v(a, blocked, omega);
+                to_lds(ph, a, blocked);
                 q += 1;
                 __syncthreads();
             };
-            for (int i = 0; i < nit; i += PF) {
-#pragma unroll
-                for (int d = 0; d < PF; d++) it(pre[d], pmw[d]);
+            for (int i = 0; i < nit; i += 4) {
+                it(std::integral_constant<int, 0>{}, pre[0], pmw[0]);
+                it(std::integral_constant<int, 1>{}, pre[1], pmw[1]);
+                it(std::integral_constant<int, 2>{}, pre[0], pmw[0]);
+                it(std::integral_constant<int, 3>{}, pre[1], pmw[1]);
             }
         } else {
-            for (int i = 0; i < nit; i++) {
-                f2 a[Q];
-                const uint8_t* fl = flags + (q & (C::FROWS - 1)) * C::RW + cx;
-                const bool b0 = fl[0] != 0, b1 = fl[64] != 0;
-                gather(xedge, q, a);
-                reflect2(a, b0, b1);
-                collide2(a, b0, b1, omega);
+            ST* orow = gout + (long long)(wrap_row(clampr(q)) + G) * RS;
+            auto it = [&](auto ph) {
+                V a[Q];
+                bool blocked[CPL];
+                gather(xedge, ph, q, a, blocked);
+                reflect_v(a, blocked);
+                collide_v(a, blocked, omega);
                 if (s < T) {
-                    to_lds(q, a);
-                } else if (q >= rlo && q < rhi) {
-                    ST* orow = gout + (long long)(wrap_row(q) + G) * RS;
-                    if (stored[0]) {
+                    to_lds(ph, a, blocked);
+                } else {
+                    const bool in = q >= rlo && q < rhi;
+                    if (in) {
 #pragma unroll
-                        for (int k = 0; k < Q; k++) LBM_TB_STORE(orow + off0[0] + slot_of(k) * LANES, a[k].x);
-                    }
-                    if (stored[1]) {
+                        for (int c = 0; c < CPL; c++) {
+                            if (stored[c]) {
 #pragma unroll
-                        for (int k = 0; k < Q; k++) LBM_TB_STORE(orow + off0[1] + slot_of(k) * LANES, a[k].y);
+                                for (int k = 0; k < Q; k++)
+                                    LBM_TB_STORE(orow + off0[c] + slot_of(k) * LANES, L::get(a[k], c));
+                            }
+                        }
+                        // next row of the output; a wrapped domain restarts at row 0
+                        orow += RS;
+                        if (wrapy && wrap_row(q) == N - 1) orow = gout + (long long)G * RS;
                     }
                 }
                 q += 1;
                 __syncthreads();
+            };
+            for (int i = 0; i < nit; i += 4) {
+                it(std::integral_constant<int, 0>{});
+                it(std::integral_constant<int, 1>{});
+                it(std::integral_constant<int, 2>{});
+                it(std::integral_constant<int, 3>{});
             }
         }
     };
@@ -274,25 +330,25 @@ __global__ __launch_bounds__((TB<T, NB>::NW * 64)) void step_tb_kernel(
     else run(std::false_type{});
 }
 
-template <int XMODE, int T, int NB, typename ST>
+template <int XMODE, int T, int NB, int CPL, typename ST>
 static void launch_tb_t(const ST* gin, ST* gout, const uint64_t* mask, const Geom& geo, int row0,
                         int nrows, int Ry, hipStream_t st) {
-    using C = TB<T, NB>;
+    using C = TB<T, NB, CPL>;
     const int nstrips = (geo.M + C::SW - 1) / C::SW;
     const int nchunks = (nrows + Ry - 1) / Ry;
-    hipLaunchKernelGGL((step_tb_kernel<XMODE, T, NB, TB_PF, ST>), dim3((unsigned)(nstrips * nchunks)),
+    hipLaunchKernelGGL((step_tb_kernel<XMODE, T, NB, CPL, ST>), dim3((unsigned)(nstrips * nchunks)),
                        dim3(C::NW * 64), 0, st, gin, gout, mask, geo, row0, nrows, Ry, nstrips);
 }
 
-template <int T, int NB>
+template <int T, int NB, int CPL>
 static void launch_tb_T(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
                         bool half, int row0, int nrows, int Ry, hipStream_t st) {
     if (xmode == XMODE_PERIODIC) {
-        if (half) launch_tb_t<XMODE_PERIODIC, T, NB>((const __half*)gin, (__half*)gout, mask, geo, row0, nrows, Ry, st);
-        else launch_tb_t<XMODE_PERIODIC, T, NB>((const float*)gin, (float*)gout, mask, geo, row0, nrows, Ry, st);
+        if (half) launch_tb_t<XMODE_PERIODIC, T, NB, CPL>((const __half*)gin, (__half*)gout, mask, geo, row0, nrows, Ry, st);
+        else launch_tb_t<XMODE_PERIODIC, T, NB, CPL>((const float*)gin, (float*)gout, mask, geo, row0, nrows, Ry, st);
     } else {
-        if (half) launch_tb_t<XMODE_REFERENCE, T, NB>((const __half*)gin, (__half*)gout, mask, geo, row0, nrows, Ry, st);
-        else launch_tb_t<XMODE_REFERENCE, T, NB>((const float*)gin, (float*)gout, mask, geo, row0, nrows, Ry, st);
+        if (half) launch_tb_t<XMODE_REFERENCE, T, NB, CPL>((const __half*)gin, (__half*)gout, mask, geo, row0, nrows, Ry, st);
+        else launch_tb_t<XMODE_REFERENCE, T, NB, CPL>((const float*)gin, (float*)gout, mask, geo, row0, nrows, Ry, st);
     }
 }
 
@@ -303,9 +359,9 @@ hipError_t launch_step_tb(const void* gin, void* gout, const uint64_t* mask, con
     if (nrows <= 0) return hipSuccess;
     if (Ry < 1) Ry = 1;
     switch (T) {
-        case 2: launch_tb_T<2, 4>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
-        case 3: launch_tb_T<3, 4>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
-        case 4: launch_tb_T<4, 4>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
+        case 2: launch_tb_T<2, LBM_TB_NB2, LBM_TB_CPL2>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
+        case 3: launch_tb_T<3, LBM_TB_NB3, LBM_TB_CPL3>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
+        case 4: launch_tb_T<4, LBM_TB_NB4, LBM_TB_CPL4>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
