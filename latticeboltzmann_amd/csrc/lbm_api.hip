@@ -112,7 +112,7 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     s->half = cfg->storage == LBM_STORE_F16;
     s->T = cfg->inner_timesteps;
     s->tb_max = TB_MAX_T;
-    s->tb_rows = 256;
+    s->tb_rows = 0;  // 0 = chosen per launch (auto_chunk_rows)
     Geom& g = s->geo;
     g.N = cfg->N;
     g.M = cfg->M;
@@ -334,8 +334,8 @@ int lbm_fused_collide_stream(lbm_solver* s, int n_outer) {
 
 int lbm_set_tuning(lbm_solver* s, int tb_max_depth, int tb_rows) {
     ENTER(s);
-    if (tb_max_depth < 1 || tb_max_depth > TB_MAX_T || tb_rows < 1)
-        return fail(LBM_ERR_INVALID, "tb_max_depth must be in [1, %d] and tb_rows >= 1", TB_MAX_T);
+    if (tb_max_depth < 1 || tb_max_depth > TB_MAX_T || tb_rows < 0)
+        return fail(LBM_ERR_INVALID, "tb_max_depth must be in [1, %d] and tb_rows >= 0", TB_MAX_T);
     s->tb_max = tb_max_depth;
     s->tb_rows = tb_rows;
     return LBM_OK;

@@ -30,13 +30,15 @@
 
 #include "lbm_internal.h"
 
+// Window width (NB 64-column blocks) and cells per lane for each launch depth, from sweeps on
+// MI355X at 16384 x 16384 (gpurun_out/qb_tb13.log): T=2 130, T=3 208, T=4 237 GLUPS.
 #ifndef LBM_TB_NB2
-#define LBM_TB_NB2 4
-#define LBM_TB_CPL2 1
+#define LBM_TB_NB2 8
+#define LBM_TB_CPL2 2
 #endif
 #ifndef LBM_TB_NB3
-#define LBM_TB_NB3 4
-#define LBM_TB_CPL3 1
+#define LBM_TB_NB3 8
+#define LBM_TB_CPL3 2
 #endif
 #ifndef LBM_TB_NB4
 #define LBM_TB_NB4 4
@@ -330,11 +332,41 @@ __global__ __launch_bounds__((TB<T, NB, CPL>::NW * 64)) void step_tb_kernel(
     else run(std::false_type{});
 }
 
+// Rows per workgroup chunk.  A workgroup runs Ry + 3(T-1) iterations, and the grid is executed
+// in rounds of (CUs x resident workgroups per CU): pick the Ry in [64, 512] that minimises
+// rounds x iterations (tail effect and pipeline warm-up against each other).
+static int auto_chunk_rows(int nrows, int nstrips, int T, int capacity) {
+    long long best_cost = -1;
+    int best = nrows < 64 ? (nrows > 0 ? nrows : 1) : 64;
+    for (int ry = 512; ry >= 64; ry -= 8) {
+        if (ry > nrows && ry != 64) continue;
+        const int r = ry < nrows ? ry : nrows;
+        const long long wgs = (long long)nstrips * ((nrows + r - 1) / r);
+        const long long rounds = (wgs + capacity - 1) / capacity;
+        const long long cost = rounds * (r + 3 * (T - 1));
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
+    }
+    return best;
+}
+
 template <int XMODE, int T, int NB, int CPL, typename ST>
 static void launch_tb_t(const ST* gin, ST* gout, const uint64_t* mask, const Geom& geo, int row0,
                         int nrows, int Ry, hipStream_t st) {
     using C = TB<T, NB, CPL>;
     const int nstrips = (geo.M + C::SW - 1) / C::SW;
+    if (Ry <= 0) {
+        static int capacity = 0;  // per process: all devices of a node are the same part
+        if (capacity == 0) {
+            int dev = 0, cus = 256, per_cu = 1;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                    &per_cu, step_tb_kernel<XMODE, T, NB, CPL, ST>, C::NW * 64, 0) != hipSuccess || per_cu < 1)
+                per_cu = 1;
+            capacity = cus * per_cu;
+        }
+        Ry = auto_chunk_rows(nrows, nstrips, T, capacity);
+    }
     const int nchunks = (nrows + Ry - 1) / Ry;
     hipLaunchKernelGGL((step_tb_kernel<XMODE, T, NB, CPL, ST>), dim3((unsigned)(nstrips * nchunks)),
                        dim3(C::NW * 64), 0, st, gin, gout, mask, geo, row0, nrows, Ry, nstrips);
@@ -357,7 +389,6 @@ static void launch_tb_T(const void* gin, void* gout, const uint64_t* mask, const
 hipError_t launch_step_tb(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
                           bool half, int T, int row0, int nrows, int Ry, hipStream_t st) {
     if (nrows <= 0) return hipSuccess;
-    if (Ry < 1) Ry = 1;
     switch (T) {
         case 2: launch_tb_T<2, LBM_TB_NB2, LBM_TB_CPL2>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
         case 3: launch_tb_T<3, LBM_TB_NB3, LBM_TB_CPL3>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;

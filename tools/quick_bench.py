@@ -10,7 +10,7 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
     boundary = sys.argv[4] if len(sys.argv) > 4 else "periodic"
     T = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-    tb_rows = int(sys.argv[6]) if len(sys.argv) > 6 else 256
+    tb_rows = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     s = Solver(N, M, 1e-14, inner_timesteps=T, boundary=boundary)
     from oracle import lbm_numpy as onp
     s.set_surroundings(onp.ambient())
