@@ -112,6 +112,10 @@ int lbm_init_blocked_discs(lbm_solver* s, int ndiscs, int radius, uint64_t seed,
  * (lb_cuda_kernel.cu:371-385) and the buffer swap (latticeboltzmann.py:202).  Asynchronous. --- */
 /* n_outer outer iterations of inner_timesteps updates each. */
 int lbm_fused_collide_stream(lbm_solver* s, int n_outer);
+/* Exactly n_updates lattice updates, independent of inner_timesteps, in the deepest launches the
+ * tuning and (at slab seams) the valid ghost rows allow.  No reference counterpart: the slab
+ * schedule needs update counts that are not multiples of INNER_TIMESTEPS. */
+int lbm_advance(lbm_solver* s, int n_updates);
 /* One outer iteration, then (if frame != NULL) render the new state into the caller's host
  * buffer uint8 (N, M, 3) as lb_cuda_kernel.cu:27-67,308-319 does; frame == NULL is the plain step,
  * as in latticeboltzmann.py:195-196.  The frame is complete after lbm_sync. */

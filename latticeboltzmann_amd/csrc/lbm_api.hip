@@ -332,6 +332,12 @@ int lbm_fused_collide_stream(lbm_solver* s, int n_outer) {
     return LBM_OK;
 }
 
+int lbm_advance(lbm_solver* s, int n_updates) {
+    ENTER(s);
+    if (n_updates < 0) return fail(LBM_ERR_INVALID, "n_updates < 0");
+    return advance(s, n_updates, std::max(1, std::min(s->tb_max, TB_MAX_T)));
+}
+
 int lbm_set_tuning(lbm_solver* s, int tb_max_depth, int tb_rows) {
     ENTER(s);
     if (tb_max_depth < 1 || tb_max_depth > TB_MAX_T || tb_rows < 0)

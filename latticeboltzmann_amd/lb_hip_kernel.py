@@ -29,7 +29,7 @@ SYMBOLS = [
     "lbm_fused_collide_stream_display", "lbm_step_rows", "lbm_fused_collide_stream_timed",
     "lbm_sync", "lbm_steps_done", "lbm_read_cells", "lbm_read_moments", "lbm_read_blocked",
     "lbm_render", "lbm_halo_region", "lbm_mask_halo_region", "lbm_halo_valid",
-    "lbm_halo_mark_filled", "lbm_set_tuning",
+    "lbm_halo_mark_filled", "lbm_set_tuning", "lbm_advance",
 ]
 
 
@@ -98,6 +98,7 @@ def load_library(path=LIB_PATH):
         "lbm_halo_valid": ([H, ctypes.POINTER(c_int)], c_int),
         "lbm_halo_mark_filled": ([H], c_int),
         "lbm_set_tuning": ([H, c_int, c_int], c_int),
+        "lbm_advance": ([H, c_int], c_int),
     }
     assert set(protos) == set(SYMBOLS)
     for name, (argtypes, restype) in protos.items():
@@ -207,6 +208,10 @@ class Solver:
     # -- the hot path (prepared_async_call + swap, latticeboltzmann.py:187-202) -------------------
     def fused_collide_stream(self, n_outer=1):
         _check(self._L.lbm_fused_collide_stream(self._h, n_outer))
+
+    def advance(self, n_updates):
+        """Exactly n_updates lattice updates (deepest launches the tuning / ghost rows allow)."""
+        _check(self._L.lbm_advance(self._h, n_updates))
 
     def fused_collide_stream_display(self, frame=None):
         """frame: None (plain step, latticeboltzmann.py:195-196) or a C-contiguous uint8 (N, M, 3)

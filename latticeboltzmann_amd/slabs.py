@@ -90,7 +90,8 @@ class SlabSolver:
     """One rank's slab.  torch is used for streams, events and torch.distributed only."""
 
     def __init__(self, global_rows, M, omega, rank, world, boundary="periodic", halo=4,
-                 dtype=np.float32, device=None, dist=None, group=None, host_staged=None):
+                 dtype=np.float32, device=None, dist=None, group=None, host_staged=None,
+                 tb_max_depth=1):
         import torch
         self.torch = torch
         self.dist = dist
@@ -108,6 +109,7 @@ class SlabSolver:
             self.N, M, omega, boundary=boundary, dtype=dtype, device=self.device, halo=self.halo,
             top_edge=hk.YEDGE_SEAM if self.up is not None else hk.YEDGE_DOMAIN,
             bottom_edge=hk.YEDGE_SEAM if self.down is not None else hk.YEDGE_DOMAIN)
+        self.solver.set_tuning(tb_max_depth, 0)
         self.compute = torch.cuda.Stream(device=self.device)
         self.comm = torch.cuda.Stream(device=self.device)
         self.solver.set_stream(self.compute.cuda_stream)
@@ -160,7 +162,7 @@ class SlabSolver:
     def step(self, n=1):
         """Advance by n updates (asynchronous)."""
         if self.world == 1:
-            self.solver.fused_collide_stream(n)
+            self.solver.advance(n)
             return
         advance(self, n)
 
@@ -173,7 +175,7 @@ class SlabSolver:
 
     def full_updates(self, k):
         self._wait_pending()
-        self.solver.fused_collide_stream(k)
+        self.solver.advance(k)  # LDS temporal blocking when tb_max_depth > 1 (set_tuning)
         self._fresh = False
 
     def edge_update(self):

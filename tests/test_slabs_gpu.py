@@ -72,3 +72,43 @@ def test_device_memory_wraps_as_torch_tensor():
     assert t.data_ptr() == ptr and t.numel() == nbytes and t.is_cuda
     assert nbytes == 2 * 1 * 9 * 64 * 4
     s.close()
+
+
+def _worker_tb(rank, world, port, outdir):
+    """Slabs with LDS temporal blocking inside a cycle (halo 6, launches up to 3 deep)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from latticeboltzmann_amd.slabs import SlabSolver
+    from oracle import lbm_numpy as onp
+    from oracle import lbm_ref as oc
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                            world_size=world)
+    try:
+        G, M = 160, 300
+        rng = np.random.default_rng(12)
+        blocked = rng.random((G, M)) < 0.05
+        cells = onp.perturbed_cells(G, M, seed=6, amp=0.05)
+        surr = onp.ambient()
+        slab = SlabSolver(G, M, 0.2, rank, world, boundary="periodic", halo=6, device=0, dist=dist,
+                          tb_max_depth=3)
+        slab.set_surroundings(surr)
+        slab.upload_global(cells, blocked)
+        ref = cells.copy()
+        for n in (7, 12, 5):
+            slab.step(n)
+            oc.run(ref, blocked, n, 0.2, surr, "periodic")
+            got = slab.read_cells()
+            want = ref[slab.row_lo:slab.row_hi]
+            assert np.array_equal(got, want), (rank, n, np.abs(got - want).max())
+        slab.close()
+        open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_slabs_with_temporal_blocking(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_tb, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(2))
