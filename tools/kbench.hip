@@ -13,7 +13,7 @@ using namespace lbm;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { F_NT_ST = 1, F_NT_LD = 2, F_NO_REMAP = 4, F_ROWS4 = 8, F_PERSIST = 16, F_TWO = 32 };
+enum { F_NT_ST = 1, F_NT_LD = 2, F_NO_REMAP = 4, F_ROWS4 = 8, F_PERSIST = 16, F_TWO = 32, F_PK = 64, F_PKROW = 128 };
 
 template <int FLAGS>
 __device__ __forceinline__ float ldx(const float* p) {
@@ -82,6 +82,30 @@ __global__ __launch_bounds__(256) void kvar(const float* __restrict__ gin, float
         return;
     }
     const unsigned wg = (FLAGS & F_NO_REMAP) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+    if (FLAGS & (F_PK | F_PKROW)) {
+        // two tiles per wave on packed fp32: F_PK = blocks xb, xb+1 of one row; F_PKROW = rows y, y+1
+        const long long t = (long long)wg * 4 + wave;
+        int y0, y1, xb0, xb1;
+        if (FLAGS & F_PK) { y0 = y1 = (int)(t / (geo.Mb / 2)); xb0 = 2 * (int)(t % (geo.Mb / 2)); xb1 = xb0 + 1; }
+        else { y0 = 2 * (int)(t / geo.Mb); y1 = y0 + 1; xb0 = xb1 = (int)(t % geo.Mb); }
+        float a[Q], b[Q];
+        pullp<FLAGS>(gin, geo, y0, xb0, lane, a);
+        pullp<FLAGS>(gin, geo, y1, xb1, lane, b);
+        const bool bl0 = (mask[(long long)y0 * geo.Mb + xb0] >> lane) & 1ull;
+        const bool bl1 = (mask[(long long)y1 * geo.Mb + xb1] >> lane) & 1ull;
+        f2 v[Q];
+#pragma unroll
+        for (int k = 0; k < Q; k++) v[k] = f2{a[k], b[k]};
+        reflect2(v, bl0, bl1);
+        collide2(v, bl0, bl1, geo.omega);
+        float* o0 = gout + (long long)y0 * geo.rowStride + (long long)xb0 * CHUNK + lane;
+        float* o1 = gout + (long long)y1 * geo.rowStride + (long long)xb1 * CHUNK + lane;
+#pragma unroll
+        for (int k = 0; k < Q; k++) stx<FLAGS>(o0 + slot_of(k) * LANES, v[k].x);
+#pragma unroll
+        for (int k = 0; k < Q; k++) stx<FLAGS>(o1 + slot_of(k) * LANES, v[k].y);
+        return;
+    }
     if (FLAGS & F_TWO) {
         // a wave does two vertically adjacent tiles (18 loads in flight)
         const long long t = (long long)wg * 4 + wave;  // index over (N/2) x Mb
@@ -126,7 +150,7 @@ __global__ void initk(float* f, Geom geo) {
 struct Var { const char* name; void (*fn)(const float*, float*, const uint64_t*, Geom); int div; bool persist; };
 
 template <int FLAGS> static Var mk(const char* n) {
-    return Var{n, kvar<FLAGS>, (FLAGS & F_TWO) ? 2 : 1, (FLAGS & F_PERSIST) != 0};
+    return Var{n, kvar<FLAGS>, (FLAGS & (F_TWO | F_PK | F_PKROW)) ? 2 : 1, (FLAGS & F_PERSIST) != 0};
 }
 
 int main(int argc, char** argv) {
@@ -144,7 +168,8 @@ int main(int argc, char** argv) {
     std::vector<Var> vars = {
         mk<0>("base"), mk<F_NT_ST>("nt_store"), mk<F_NT_ST | F_NT_LD>("nt_both"), mk<F_NT_LD>("nt_load"),
         mk<F_NO_REMAP>("no_remap"), mk<F_ROWS4>("rows4"), mk<F_ROWS4 | F_NT_ST>("rows4_ntst"),
-        mk<F_PERSIST>("persist"), mk<F_TWO>("two_rows"), mk<F_TWO | F_NT_ST>("two_rows_ntst"),
+        mk<F_TWO | F_NT_ST>("two_rows_ntst"), mk<F_PK | F_NT_ST>("pk_cols_ntst"), mk<F_PKROW | F_NT_ST>("pk_rows_ntst"),
+        mk<F_PK>("pk_cols"), mk<F_PK | F_NT_ST | F_NT_LD>("pk_cols_ntboth"),
     };
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<std::vector<float>> ms(vars.size());
