@@ -52,6 +52,10 @@ __device__ __forceinline__ float ld(const float* p) { return *p; }
 __device__ __forceinline__ float ld(const __half* p) { return __half2float(*p); }
 __device__ __forceinline__ void st(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st(__half* p, float v) { *p = __float2half_rn(v); }
+__device__ __forceinline__ float ld_nt(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float ld_nt(const __half* p) {
+    return __half2float(__ushort_as_half(__builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(p))));
+}
 // streaming (non-temporal) store: the new state is not re-read before the next launch
 __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void st_nt(__half* p, float v) {

@@ -33,7 +33,7 @@
 // Window width (NB 64-column blocks) and cells per lane for each launch depth, from sweeps on
 // MI355X at 16384 x 16384 (gpurun_out/qb_tb13.log): T=2 130, T=3 208, T=4 237 GLUPS.
 #ifndef LBM_TB_NB2
-#define LBM_TB_NB2 8
+#define LBM_TB_NB2 16
 #define LBM_TB_CPL2 2
 #endif
 #ifndef LBM_TB_NB3
@@ -44,23 +44,34 @@
 #define LBM_TB_NB4 4
 #define LBM_TB_CPL4 2
 #endif
-#ifndef LBM_TB_MARG
-#define LBM_TB_MARG 8
+#ifndef LBM_TB_MARG2
+#define LBM_TB_MARG2 16
+#endif
+#ifndef LBM_TB_MARG3
+#define LBM_TB_MARG3 16
+#endif
+#ifndef LBM_TB_MARG4
+#define LBM_TB_MARG4 8
 #endif
 #ifndef LBM_TB_STORE
 #define LBM_TB_STORE st
 #endif
+#ifndef LBM_TB_LOAD
+#define LBM_TB_LOAD ld
+#endif
+#ifndef LBM_TB_REMAP
+#define LBM_TB_REMAP 1
+#endif
 
 namespace lbm {
 
-constexpr int TB_MARG = LBM_TB_MARG;  // window columns on either side that are computed but not stored
 
-template <int T, int NB, int CPL>
+template <int T, int NB, int CPL, int MARG>
 struct TB {
-    static_assert(T - 1 <= TB_MARG, "margin too small for this depth");
+    static_assert(T - 1 <= MARG, "margin too small for this depth");
     static_assert(NB % CPL == 0, "a lane owns CPL 64-column blocks");
     static constexpr int W = NB * 64;            // window width (columns computed per stage)
-    static constexpr int SW = W - 2 * TB_MARG;   // strip width (columns stored)
+    static constexpr int SW = W - 2 * MARG;      // strip width (columns stored)
     static constexpr int RW = W + 2;             // floats per slot row (+1 pad either side)
     static constexpr int ROWB = (37 * RW + 15) / 16 * 16;  // ring row: 9 fp32 slots + a flag byte row, 16-B aligned
     static constexpr int LEVB = 4 * ROWB;        // bytes per level (ring of 4 rows)
@@ -90,19 +101,21 @@ __device__ __forceinline__ void collide_v(f2* a, const bool* b, float om) { coll
 // (i+1) & 3, (i+2) & 3, (i+3) & 3.  The row loop is unrolled by four, so every LDS address is a
 // per-lane base plus a compile-time offset.  A cell's blocked flag travels through the rings as
 // a tenth, one-byte "slot": only stage 1 reads the bit-packed mask.
-template <int XMODE, int T, int NB, int CPL, typename ST>
-__global__ __launch_bounds__((TB<T, NB, CPL>::NW * 64)) void step_tb_kernel(
+template <int XMODE, int T, int NB, int CPL, int MARG, typename ST>
+__global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kernel(
     const ST* __restrict__ gin, ST* __restrict__ gout, const uint64_t* __restrict__ mask, Geom geo,
     int row0, int nrows, int Ry, int nstrips) {
-    using C = TB<T, NB, CPL>;
+    using C = TB<T, NB, CPL, MARG>;
     using L = LaneV<CPL>;
     using V = typename L::V;
     constexpr int PF = 2;  // stage-1 rows in flight
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDSB];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int strip = wg % nstrips, chunk = wg / nstrips;
+    const unsigned wg = LBM_TB_REMAP == 1 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int nchunks_ = gridDim.x / nstrips;
+    const int strip = LBM_TB_REMAP == 2 ? wg / nchunks_ : wg % nstrips;
+    const int chunk = LBM_TB_REMAP == 2 ? wg % nchunks_ : wg / nstrips;
     const int xo = strip * C::SW;  // first stored column
     const int y0 = row0 + chunk * Ry;
     const int y1 = min(y0 + Ry, row0 + nrows);
@@ -131,7 +144,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL>::NW * 64)) void step_tb_kernel(
     bool any_xedge = false;
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
-        const int x = xo - TB_MARG + j * (64 * CPL) + c * 64 + lane;  // logical column
+        const int x = xo - MARG + j * (64 * CPL) + c * 64 + lane;  // logical column
         int xn;                                                       // storage column
         if (XMODE == XMODE_PERIODIC) { xn = x % M; if (xn < 0) xn += M; }
         else xn = min(max(x, 0), M - 1);  // outside the domain: a valid address, never stored
@@ -194,9 +207,9 @@ __global__ __launch_bounds__((TB<T, NB, CPL>::NW * 64)) void step_tb_kernel(
                 if (decltype(xedge)::value) {
                     const bool ox = dx == 1 ? ob_p[c] : (dx == -1 ? ob_m[c] : false);
                     const ST* pp = ox ? (p0 + off0[c]) : (rb + off);
-                    v[c] = ld(pp + sl);
+                    v[c] = LBM_TB_LOAD(pp + sl);
                 } else {
-                    v[c] = ld(rb + off + sl);
+                    v[c] = LBM_TB_LOAD(rb + off + sl);
                 }
             }
             dst[k] = L::make(v);
@@ -349,10 +362,10 @@ static int auto_chunk_rows(int nrows, int nstrips, int T, int capacity) {
     return best;
 }
 
-template <int XMODE, int T, int NB, int CPL, typename ST>
+template <int XMODE, int T, int NB, int CPL, int MARG, typename ST>
 static void launch_tb_t(const ST* gin, ST* gout, const uint64_t* mask, const Geom& geo, int row0,
                         int nrows, int Ry, hipStream_t st) {
-    using C = TB<T, NB, CPL>;
+    using C = TB<T, NB, CPL, MARG>;
     const int nstrips = (geo.M + C::SW - 1) / C::SW;
     if (Ry <= 0) {
         static int capacity = 0;  // per process: all devices of a node are the same part
@@ -361,26 +374,26 @@ static void launch_tb_t(const ST* gin, ST* gout, const uint64_t* mask, const Geo
             (void)hipGetDevice(&dev);
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                    &per_cu, step_tb_kernel<XMODE, T, NB, CPL, ST>, C::NW * 64, 0) != hipSuccess || per_cu < 1)
+                    &per_cu, step_tb_kernel<XMODE, T, NB, CPL, MARG, ST>, C::NW * 64, 0) != hipSuccess || per_cu < 1)
                 per_cu = 1;
             capacity = cus * per_cu;
         }
         Ry = auto_chunk_rows(nrows, nstrips, T, capacity);
     }
     const int nchunks = (nrows + Ry - 1) / Ry;
-    hipLaunchKernelGGL((step_tb_kernel<XMODE, T, NB, CPL, ST>), dim3((unsigned)(nstrips * nchunks)),
+    hipLaunchKernelGGL((step_tb_kernel<XMODE, T, NB, CPL, MARG, ST>), dim3((unsigned)(nstrips * nchunks)),
                        dim3(C::NW * 64), 0, st, gin, gout, mask, geo, row0, nrows, Ry, nstrips);
 }
 
-template <int T, int NB, int CPL>
+template <int T, int NB, int CPL, int MARG>
 static void launch_tb_T(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
                         bool half, int row0, int nrows, int Ry, hipStream_t st) {
     if (xmode == XMODE_PERIODIC) {
-        if (half) launch_tb_t<XMODE_PERIODIC, T, NB, CPL>((const __half*)gin, (__half*)gout, mask, geo, row0, nrows, Ry, st);
-        else launch_tb_t<XMODE_PERIODIC, T, NB, CPL>((const float*)gin, (float*)gout, mask, geo, row0, nrows, Ry, st);
+        if (half) launch_tb_t<XMODE_PERIODIC, T, NB, CPL, MARG>((const __half*)gin, (__half*)gout, mask, geo, row0, nrows, Ry, st);
+        else launch_tb_t<XMODE_PERIODIC, T, NB, CPL, MARG>((const float*)gin, (float*)gout, mask, geo, row0, nrows, Ry, st);
     } else {
-        if (half) launch_tb_t<XMODE_REFERENCE, T, NB, CPL>((const __half*)gin, (__half*)gout, mask, geo, row0, nrows, Ry, st);
-        else launch_tb_t<XMODE_REFERENCE, T, NB, CPL>((const float*)gin, (float*)gout, mask, geo, row0, nrows, Ry, st);
+        if (half) launch_tb_t<XMODE_REFERENCE, T, NB, CPL, MARG>((const __half*)gin, (__half*)gout, mask, geo, row0, nrows, Ry, st);
+        else launch_tb_t<XMODE_REFERENCE, T, NB, CPL, MARG>((const float*)gin, (float*)gout, mask, geo, row0, nrows, Ry, st);
     }
 }
 
@@ -390,9 +403,9 @@ hipError_t launch_step_tb(const void* gin, void* gout, const uint64_t* mask, con
                           bool half, int T, int row0, int nrows, int Ry, hipStream_t st) {
     if (nrows <= 0) return hipSuccess;
     switch (T) {
-        case 2: launch_tb_T<2, LBM_TB_NB2, LBM_TB_CPL2>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
-        case 3: launch_tb_T<3, LBM_TB_NB3, LBM_TB_CPL3>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
-        case 4: launch_tb_T<4, LBM_TB_NB4, LBM_TB_CPL4>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
+        case 2: launch_tb_T<2, LBM_TB_NB2, LBM_TB_CPL2, LBM_TB_MARG2>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
+        case 3: launch_tb_T<3, LBM_TB_NB3, LBM_TB_CPL3, LBM_TB_MARG3>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
+        case 4: launch_tb_T<4, LBM_TB_NB4, LBM_TB_CPL4, LBM_TB_MARG4>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
