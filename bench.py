@@ -104,11 +104,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        # RCCL on a real node; LBM_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks
+        # on one GPU (halos staged through the host), never for a reported number
+        backend = os.environ.get("LBM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     rows, cols = args.rows, args.cols
     surr = onp.ambient()
@@ -171,7 +178,8 @@ def main():
         dist.barrier()
         wall = time.perf_counter() - t0
         kernel_ms = ev0.elapsed_time(ev1)
-        t = torch.tensor([wall, kernel_ms], device=f"cuda:{local_rank}", dtype=torch.float64)
+        t = torch.tensor([wall, kernel_ms], dtype=torch.float64,
+                         device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, kernel_ms = float(t[0]), float(t[1])
         u, rho = slab.read_moments(rows=(0, 8), cols=(0, 64))

@@ -213,8 +213,27 @@ __device__ __forceinline__ void moments2(const f2 a[Q], f2& p, f2& u0, f2& u1) {
     m0 = m0 + a[2]; m0 = m0 - a[3]; m0 = m0 + a[5]; m0 = m0 - a[6]; m0 = m0 + a[8];
     f2 m1 = 0.0f - a[0];
     m1 = m1 - a[1]; m1 = m1 - a[2]; m1 = m1 + a[6]; m1 = m1 + a[7]; m1 = m1 + a[8];
+#ifdef LBM_FAST_DIV
+    {   // EXPERIMENT: the unscaled core of the IEEE division expansion, shared reciprocal
+        const f2 r0 = f2{__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
+        const f2 one = f2{1.0f, 1.0f};
+        f2 e = __builtin_elementwise_fma(-p, r0, one);
+        const f2 r = __builtin_elementwise_fma(e, r0, r0);
+        f2 q = m0 * r;
+        e = __builtin_elementwise_fma(-p, q, m0);
+        q = __builtin_elementwise_fma(e, r, q);
+        e = __builtin_elementwise_fma(-p, q, m0);
+        u0 = __builtin_elementwise_fma(e, r, q);
+        q = m1 * r;
+        e = __builtin_elementwise_fma(-p, q, m1);
+        q = __builtin_elementwise_fma(e, r, q);
+        e = __builtin_elementwise_fma(-p, q, m1);
+        u1 = __builtin_elementwise_fma(e, r, q);
+    }
+#else
     u0 = m0 / p;  // two IEEE divisions each
     u1 = m1 / p;
+#endif
     const float inf = __builtin_inff();
     if (__any(!(__builtin_fabsf(u0.x) < inf) || !(__builtin_fabsf(u0.y) < inf) ||
               !(__builtin_fabsf(u1.x) < inf) || !(__builtin_fabsf(u1.y) < inf))) {
