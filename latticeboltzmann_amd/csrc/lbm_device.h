@@ -213,30 +213,41 @@ __device__ __forceinline__ void moments2(const f2 a[Q], f2& p, f2& u0, f2& u1) {
     m0 = m0 + a[2]; m0 = m0 - a[3]; m0 = m0 + a[5]; m0 = m0 - a[6]; m0 = m0 + a[8];
     f2 m1 = 0.0f - a[0];
     m1 = m1 - a[1]; m1 = m1 - a[2]; m1 = m1 + a[6]; m1 = m1 + a[7]; m1 = m1 + a[8];
-#ifdef LBM_FAST_DIV
-    {   // EXPERIMENT: the unscaled core of the IEEE division expansion, shared reciprocal
-        const f2 r0 = f2{__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
-        const f2 one = f2{1.0f, 1.0f};
-        f2 e = __builtin_elementwise_fma(-p, r0, one);
-        const f2 r = __builtin_elementwise_fma(e, r0, r0);
-        f2 q = m0 * r;
-        e = __builtin_elementwise_fma(-p, q, m0);
-        q = __builtin_elementwise_fma(e, r, q);
-        e = __builtin_elementwise_fma(-p, q, m0);
-        u0 = __builtin_elementwise_fma(e, r, q);
-        q = m1 * r;
-        e = __builtin_elementwise_fma(-p, q, m1);
-        q = __builtin_elementwise_fma(e, r, q);
-        e = __builtin_elementwise_fma(-p, q, m1);
-        u1 = __builtin_elementwise_fma(e, r, q);
-    }
-#else
-    u0 = m0 / p;  // two IEEE divisions each
-    u1 = m1 / p;
-#endif
-    const float inf = __builtin_inff();
-    if (__any(!(__builtin_fabsf(u0.x) < inf) || !(__builtin_fabsf(u0.y) < inf) ||
-              !(__builtin_fabsf(u1.x) < inf) || !(__builtin_fabsf(u1.y) < inf))) {
+    // Division.  `m / p` expands to v_div_scale x2, v_rcp, 7 FMAs, v_div_fmas, v_div_fixup per
+    // quotient, all scalar: 44 instructions for the four quotients of a lane.  The scale / fixup
+    // parts only act on extreme operands, so the common case runs the same refinement unscaled,
+    // on packed FMAs, with ONE reciprocal per cell (14 instructions).  It is bit-identical to the
+    // IEEE quotient whenever v_div_scale would not have scaled: p, m0, m1 have frexp exponents in
+    // [-80, 40] (0 for a zero operand) and |u| < 2^40 -- i.e. denominator and reciprocal normal,
+    // quotient normal, numerator not tiny, exponent difference < 96.  Any lane outside that range
+    // (or non-finite) sends its wave down the exact path, which also applies np.nan_to_num.
+    // (A -0 numerator gives +0 instead of -0 on the fast path; no later operation can see it.)
+    const f2 r0 = f2{__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
+    const f2 one = f2{1.0f, 1.0f};
+    f2 e = __builtin_elementwise_fma(-p, r0, one);
+    const f2 r = __builtin_elementwise_fma(e, r0, r0);
+    f2 q = m0 * r;
+    e = __builtin_elementwise_fma(-p, q, m0);
+    q = __builtin_elementwise_fma(e, r, q);
+    e = __builtin_elementwise_fma(-p, q, m0);
+    u0 = __builtin_elementwise_fma(e, r, q);
+    q = m1 * r;
+    e = __builtin_elementwise_fma(-p, q, m1);
+    q = __builtin_elementwise_fma(e, r, q);
+    e = __builtin_elementwise_fma(-p, q, m1);
+    u1 = __builtin_elementwise_fma(e, r, q);
+    const int ex0 = __builtin_amdgcn_frexp_expf(p.x), ex1 = __builtin_amdgcn_frexp_expf(m0.x),
+              ex2 = __builtin_amdgcn_frexp_expf(m1.x), ey0 = __builtin_amdgcn_frexp_expf(p.y),
+              ey1 = __builtin_amdgcn_frexp_expf(m0.y), ey2 = __builtin_amdgcn_frexp_expf(m1.y);
+    const int emin = min(min(min(ex0, ex1), ex2), min(min(ey0, ey1), ey2));
+    const int emax = max(max(max(ex0, ex1), ex2), max(max(ey0, ey1), ey2));
+    const float big = 1099511627776.0f;  // 2^40
+    const bool odd = emin < -80 || emax > 40 ||
+                     !(__builtin_fabsf(u0.x) < big) || !(__builtin_fabsf(u0.y) < big) ||
+                     !(__builtin_fabsf(u1.x) < big) || !(__builtin_fabsf(u1.y) < big);
+    if (__any(odd)) {
+        u0 = m0 / p;  // IEEE divisions
+        u1 = m1 / p;
         u0 = f2{nan_to_num(u0.x), nan_to_num(u0.y)};
         u1 = f2{nan_to_num(u1.x), nan_to_num(u1.y)};
     }

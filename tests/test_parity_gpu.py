@@ -122,3 +122,35 @@ def test_zero_density_and_non_finite_cells():
             onp.run(refn, blocked, 2 * T, 0.5)
         assert np.array_equal(refn, ref, equal_nan=True)  # the C twin follows numpy here too
         s.close()
+
+
+@pytest.mark.parametrize("T", [1, 2, 4])
+def test_extreme_magnitudes_take_the_exact_division_path(T):
+    """The packed kernels divide on a shared-reciprocal fast path that is exact only for ordinary
+    magnitudes and must hand every other cell to the IEEE division: regions scaled to 1e-30 and
+    1e+25, mixed signs, denormal-range moments and exact zeros, against the oracle bit for bit."""
+    from latticeboltzmann_amd.lb_hip_kernel import Solver
+    N, M = 48, 640
+    rng = np.random.default_rng(99)
+    blocked = rng.random((N, M)) < 0.03
+    cells = onp.perturbed_cells(N, M, seed=8, amp=0.2)
+    cells[:, 100:200] *= np.float32(1e-30)
+    cells[:, 200:260] *= np.float32(1e-38)      # denormal populations
+    cells[:, 300:400] *= np.float32(1e25)
+    cells[10:20, 420:500] *= rng.choice(np.float32([-1, 1]), size=(10, 80, 9))
+    cells[30:35, 520:600] = 0
+    cells[40, 610] = [1e-20, 0, 0, 0, 1, 0, 0, 0, -1e-20]
+    surr = onp.ambient()
+    s = Solver(N, M, 0.4, inner_timesteps=T, boundary="periodic")
+    s.set_surroundings(surr)
+    s.upload_blocked(blocked)
+    s.upload_cells(cells)
+    ref = cells.copy()
+    with np.errstate(all="ignore"):
+        for _ in range(3):
+            s.fused_collide_stream(1)
+            oc.run(ref, blocked, T, 0.4, surr, "periodic")
+            got = s.read_cells()
+            bad = np.argwhere(~((got == ref) | (np.isnan(got) & np.isnan(ref))))
+            assert bad.size == 0, f"T={T}: {len(bad)} mismatches, first {bad[:5].tolist()}"
+    s.close()
