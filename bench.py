@@ -136,11 +136,11 @@ def main():
         if not (np.isfinite(rho).all() and np.isfinite(u).all()):
             raise SystemExit("non-finite fields after the timed region")
         solver.close()
-        # BASELINE.json configs[2]: the same grid with INNER_TIMESTEPS = 3 / 4 (LDS temporal
-        # blocking) and multi-obstacle bounce-back (seeded discs, 0.4 % blocked).  Reported beside
-        # the headline, never as `value`.
+        # BASELINE.json configs[2]: the same grid with INNER_TIMESTEPS = 4 / 5 / 6 (LDS temporal
+        # blocking, one launch per outer iteration) and multi-obstacle bounce-back (seeded discs,
+        # 0.4 % blocked).  Reported beside the headline, never as `value`.
         tb = []
-        for T in (3, 4):
+        for T in (4, 5, 6):
             s2 = hk.Solver(rows, cols, onp.OMEGA, inner_timesteps=T, boundary="periodic",
                            device=local_rank)
             s2.set_surroundings(surr)

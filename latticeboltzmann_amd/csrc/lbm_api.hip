@@ -111,7 +111,7 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     s->xmode = cfg->boundary == LBM_BOUNDARY_PERIODIC ? XMODE_PERIODIC : XMODE_REFERENCE;
     s->half = cfg->storage == LBM_STORE_F16;
     s->T = cfg->inner_timesteps;
-    s->tb_max = TB_MAX_T;
+    s->tb_max = TB_DEFAULT_T;
     s->tb_rows = 0;  // 0 = chosen per launch (auto_chunk_rows)
     Geom& g = s->geo;
     g.N = cfg->N;

@@ -6,7 +6,8 @@ namespace lbm {
 
 hipError_t launch_step(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
                        bool half, int row0, int nrows, hipStream_t st);
-constexpr int TB_MAX_T = 4;
+constexpr int TB_MAX_T = 6;      // deepest launch the LDS kernel is instantiated for
+constexpr int TB_DEFAULT_T = 6;  // deepest launch used unless lbm_set_tuning says otherwise
 hipError_t launch_step_tb(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
                           bool half, int T, int row0, int nrows, int Ry, hipStream_t st);
 hipError_t launch_collide(void* f, const uint64_t* mask, const Geom& geo, bool half, int row0,

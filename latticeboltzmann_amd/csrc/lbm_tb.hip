@@ -30,10 +30,11 @@
 
 #include "lbm_internal.h"
 
-// Window width (NB 64-column blocks) and cells per lane for each launch depth, from sweeps on
-// MI355X at 16384 x 16384 (gpurun_out/qb_tb13.log): T=2 130, T=3 208, T=4 237 GLUPS.
+// Window width (NB 64-column blocks), cells per
+// lane and margin for each launch depth, from sweeps on MI355X at 16384 x 16384 (periodic /
+// reference edges): T=2 143 / 144, T=3 213 / 184, T=4 249 / 212, T=5 241 / 202, T=6 274 / 224 GLUPS.
 #ifndef LBM_TB_NB2
-#define LBM_TB_NB2 16
+#define LBM_TB_NB2 12
 #define LBM_TB_CPL2 2
 #endif
 #ifndef LBM_TB_NB3
@@ -41,8 +42,16 @@
 #define LBM_TB_CPL3 2
 #endif
 #ifndef LBM_TB_NB4
-#define LBM_TB_NB4 4
+#define LBM_TB_NB4 6
 #define LBM_TB_CPL4 2
+#endif
+#ifndef LBM_TB_NB5
+#define LBM_TB_NB5 4
+#define LBM_TB_CPL5 2
+#endif
+#ifndef LBM_TB_NB6
+#define LBM_TB_NB6 4
+#define LBM_TB_CPL6 2
 #endif
 #ifndef LBM_TB_MARG2
 #define LBM_TB_MARG2 16
@@ -52,6 +61,12 @@
 #endif
 #ifndef LBM_TB_MARG4
 #define LBM_TB_MARG4 8
+#endif
+#ifndef LBM_TB_MARG5
+#define LBM_TB_MARG5 8
+#endif
+#ifndef LBM_TB_MARG6
+#define LBM_TB_MARG6 8
 #endif
 #ifndef LBM_TB_STORE
 #define LBM_TB_STORE st
@@ -66,17 +81,40 @@
 namespace lbm {
 
 
+// LDS image of one time level.  Each stored population is read by exactly one cell of the next
+// level: the dy = -1 populations (slots 0-2) of a row one iteration after they were written, the
+// dy = 0 ones (slots 3-5) two, the dy = +1 ones (slots 6-8) three iterations after.  So slots 0-2
+// need a ring of only DA = 2 rows, the others (and the flag bytes) 4: 124 instead of 148 bytes per
+// column and level.  The reference edge rule ("the last row / column keeps its own value",
+// latticeboltzmann.py:115-120) would read a cell's own slot 0-2 value two iterations late; instead
+//   - the stage that has just written the last domain row N-1 writes, one iteration later, a
+//     phantom row N whose slot 0-2 entries are row N-1's shifted by dx, so that the ordinary pull
+//     of row N-1 finds its own values there;
+//   - the lane of the last column M-1 also drops its slot-0 value into a 4-entry side ring
+//     (E_OFF), from which the x-edge code path takes it two iterations later.
 template <int T, int NB, int CPL, int MARG>
 struct TB {
     static_assert(T - 1 <= MARG, "margin too small for this depth");
     static_assert(NB % CPL == 0, "a lane owns CPL 64-column blocks");
+    static constexpr int DA = 2;                 // ring depth of the dy = -1 slots
     static constexpr int W = NB * 64;            // window width (columns computed per stage)
     static constexpr int SW = W - 2 * MARG;      // strip width (columns stored)
     static constexpr int RW = W + 2;             // floats per slot row (+1 pad either side)
-    static constexpr int ROWB = (37 * RW + 15) / 16 * 16;  // ring row: 9 fp32 slots + a flag byte row, 16-B aligned
-    static constexpr int LEVB = 4 * ROWB;        // bytes per level (ring of 4 rows)
+    static constexpr int A_ROW = 3 * RW * 4;     // bytes per ring row of slots 0-2
+    static constexpr int B_ROW = 6 * RW * 4;     // bytes per ring row of slots 3-8
+    static constexpr int B_OFF = DA * A_ROW;
+    static constexpr int F_OFF = B_OFF + 4 * B_ROW;          // flag bytes, ring of 4 rows of RW bytes
+    static constexpr int E_OFF = (F_OFF + 4 * RW + 3) / 4 * 4;  // last column's slot 0, ring of 4 floats
+    static constexpr int LEVB = (E_OFF + 16 + 15) / 16 * 16;    // bytes per level
     static constexpr int LDSB = (T - 1) * LEVB;
     static constexpr int NW = T * NB / CPL;      // waves: one per (stage, CPL blocks)
+    // byte offset of population slot sl in the ring row written `age` iterations before phase ph
+    static constexpr int slot_off(int sl, int ph, int age) {
+        return sl < 3 ? ((ph - age) & (DA - 1)) * A_ROW + sl * RW * 4
+                      : B_OFF + ((ph - age) & 3) * B_ROW + (sl - 3) * RW * 4;
+    }
+    static constexpr int flag_off(int ph, int age) { return F_OFF + ((ph - age) & 3) * RW; }
+    static constexpr int edge_off(int ph, int age) { return E_OFF + ((ph - age) & 3) * 4; }
 };
 
 // value type of a lane: one cell (float) or two cells 64 columns apart (packed float2)
@@ -96,9 +134,9 @@ __device__ __forceinline__ void reflect_v(f2* a, const bool* b) { reflect2(a, b[
 __device__ __forceinline__ void collide_v(float* a, const bool* b, float om) { collide(a, b[0], om); }
 __device__ __forceinline__ void collide_v(f2* a, const bool* b, float om) { collide2(a, b[0], b[1], om); }
 
-// Ring slots are addressed by ITERATION, not by row: in iteration i a stage writes its row into
-// slot i & 3 of its level, and the next stage (two rows behind) finds rows q-1, q, q+1 in slots
-// (i+1) & 3, (i+2) & 3, (i+3) & 3.  The row loop is unrolled by four, so every LDS address is a
+// Ring rows are addressed by ITERATION, not by row: in iteration i a stage writes its row into
+// ring row i mod depth of its level, and the next stage (two rows behind) finds rows q+1, q, q-1
+// in the ring rows written one, two and three iterations earlier.  The row loop is unrolled by four, so every LDS address is a
 // per-lane base plus a compile-time offset.  A cell's blocked flag travels through the rings as
 // a tenth, one-byte "slot": only stage 1 reads the bit-packed mask.
 template <int XMODE, int T, int NB, int CPL, int MARG, typename ST>
@@ -140,7 +178,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     const int cx = 1 + j * (64 * CPL) + lane;  // ring-row index of cell 0; cell c is 64*c further
     int off0[CPL], offm[CPL], offp[CPL], mblk[CPL];
     unsigned mbit[CPL];
-    bool stored[CPL], ob_m[CPL], ob_p[CPL];
+    bool stored[CPL], ob_m[CPL], ob_p[CPL], last_col[CPL];
     bool any_xedge = false;
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
@@ -152,6 +190,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         // x edge rule (reference mode only): source of dx = -1 / +1 outside the domain
         ob_m[c] = XMODE != XMODE_PERIODIC && x + 1 >= M;
         ob_p[c] = XMODE != XMODE_PERIODIC && x - 1 < 0;
+        last_col[c] = XMODE != XMODE_PERIODIC && x == M - 1;
         any_xedge = any_xedge || ob_m[c] || ob_p[c];
         int xm1 = xn + 1, xp1 = xn - 1;
         if (XMODE == XMODE_PERIODIC) { xm1 = xm1 >= M ? 0 : xm1; xp1 = xp1 < 0 ? M - 1 : xp1; }
@@ -175,12 +214,13 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     };
     auto clampr = [&](int r) { return min(max(r, rlo), rhi - 1); };
 
-    // LDS views.  Level l (1..T-1) lives at lds + (l-1)*LEVB; ring slot t at + t*ROWB; inside a
-    // slot: population slot k at float index k*RW + column, flags at byte 36*RW + column.
+    // LDS views (layout: struct TB).  Level l (1..T-1) lives at lds + (l-1)*LEVB.
     unsigned char* const wr_base = lds + (s - 1) * C::LEVB + cx * 4;  // this stage's level (s < T)
     const unsigned char* const rd_base = lds + (s - 2) * C::LEVB + cx * 4;  // level s-1 (s > 1)
-    unsigned char* const wr_flag = lds + (s - 1) * C::LEVB + 36 * C::RW + cx;
-    const unsigned char* const rd_flag = lds + (s - 2) * C::LEVB + 36 * C::RW + cx;
+    unsigned char* const wr_flag = lds + (s - 1) * C::LEVB + cx;
+    const unsigned char* const rd_flag = lds + (s - 2) * C::LEVB + cx;
+    unsigned char* const wr_lev = lds + (s - 1) * C::LEVB;        // side ring of the last column
+    const unsigned char* const rd_lev = lds + (s - 2) * C::LEVB;
 
     // stage 1: issue the CPL x 9 pulled loads of logical row r (clamped into this stage's range)
     // and the mask words.  Pure loads from always-valid addresses (a source outside the domain is
@@ -189,28 +229,41 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     auto load_row = [&](auto xedge, int r, V* dst, uint64_t* mw) {
         r = clampr(r);
         const int rn = wrap_row(r);
-        const bool ob_u = r - 1 < qlo, ob_d = r + 1 >= qhi;
+        const bool ob_u = r - 1 < qlo, ob_d = XMODE != XMODE_PERIODIC && r + 1 >= qhi;
         const int rnu = ob_u ? rn : wrap_row(r - 1), rnd = ob_d ? rn : wrap_row(r + 1);
         const ST* p0 = gin + (long long)(rn + G) * RS;
         const ST* pu = gin + (long long)(rnu + G) * RS;
         const ST* pd = gin + (long long)(rnd + G) * RS;
+        // column offsets as plain values (never select between array elements behind a branch:
+        // that turns the arrays into scratch memory).  Below the last domain row the dy = -1
+        // source is the own cell: own row (pd = p0) AND own column.
+        int o0[CPL], om[CPL], op[CPL], omd[CPL], opd[CPL];
+        bool xm[CPL], xp[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int a0 = off0[c], am = offm[c], ap = offp[c];
+            o0[c] = a0; om[c] = am; op[c] = ap;
+            omd[c] = ob_d ? a0 : am;
+            opd[c] = ob_d ? a0 : ap;
+            xm[c] = ob_m[c]; xp[c] = ob_p[c];
+        }
 #pragma unroll
         for (int k = 0; k < Q; k++) {
             const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
             const ST* rb = dy == 1 ? pu : (dy == 0 ? p0 : pd);
-            const bool oy = XMODE != XMODE_PERIODIC && (dy == 1 ? ob_u : (dy == -1 ? ob_d : false));
             float v[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
-                // a source row outside the domain falls back to the own cell: own row AND column
-                const int off = oy ? off0[c] : (dx == 1 ? offp[c] : (dx == 0 ? off0[c] : offm[c]));
-                if (decltype(xedge)::value) {
-                    const bool ox = dx == 1 ? ob_p[c] : (dx == -1 ? ob_m[c] : false);
-                    const ST* pp = ox ? (p0 + off0[c]) : (rb + off);
-                    v[c] = LBM_TB_LOAD(pp + sl);
-                } else {
-                    v[c] = LBM_TB_LOAD(rb + off + sl);
+                const int off = dx == 0 ? o0[c] : (dy == -1 ? (dx == 1 ? opd[c] : omd[c])
+                                                             : (dx == 1 ? op[c] : om[c]));
+                const ST* pp = rb + off;
+                if (decltype(xedge)::value && dx != 0) {
+                    // a source column outside the domain: the own cell (any valid address does
+                    // for dx = +1, which inlet_fix overwrites)
+                    const ST* own = p0 + o0[c];
+                    pp = (dx == 1 ? xp[c] : xm[c]) ? own : pp;
                 }
+                v[c] = LBM_TB_LOAD(pp + sl);
             }
             dst[k] = L::make(v);
         }
@@ -238,40 +291,67 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     // blocked flags from the ring of level s-1
     auto gather = [&](auto xedge, auto ph, int r, V* a, bool* blocked) {
         constexpr int PH = decltype(ph)::value;
-        constexpr int SU = ((PH + 1) & 3) * C::ROWB, S0 = ((PH + 2) & 3) * C::ROWB,
-                      SD = ((PH + 3) & 3) * C::ROWB;
+        // the previous stage wrote row r+1 one, row r two and row r-1 three iterations ago (below
+        // the last domain row: the phantom row, which holds this row's own dy = -1 values)
 #pragma unroll
-        for (int c = 0; c < CPL; c++) blocked[c] = rd_flag[S0 + 64 * c] != 0;
+        for (int c = 0; c < CPL; c++) blocked[c] = rd_flag[C::flag_off(PH, 2) + 64 * c] != 0;
         const bool ob_u = XMODE != XMODE_PERIODIC && r - 1 < qlo;
-        const bool ob_d = XMODE != XMODE_PERIODIC && r + 1 >= qhi;
 #pragma unroll
         for (int k = 0; k < Q; k++) {
-            const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * C::RW * 4;
-            const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
-            const int ro = dy == 1 ? SU : (dy == 0 ? S0 : SD);
+            const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k);
+            const int src = C::slot_off(sl, PH, dy == 1 ? 3 : (dy == 0 ? 2 : 1)) - 4 * dx;
             float v[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
-                const bool ox = decltype(xedge)::value && (dx == 1 ? ob_p[c] : (dx == -1 ? ob_m[c] : false));
-                // own-cell fallback (own row AND own column) when the source is outside the domain
-                const int o = (oy || ox) ? S0 : ro - 4 * dx;
-                v[c] = *reinterpret_cast<const float*>(rd_base + o + sl + 256 * c);
+                v[c] = *reinterpret_cast<const float*>(rd_base + src + 256 * c);
+                if (decltype(xedge)::value && dx == -1) {
+                    // source column M is outside the domain: the own cell's value (own row AND
+                    // column), two iterations old; slot 0 has left its 2-row ring, see edge_off
+                    const float own = sl == 0
+                        ? *reinterpret_cast<const float*>(rd_lev + C::edge_off(PH, 2))
+                        : *reinterpret_cast<const float*>(rd_base + C::slot_off(sl, PH, 2) + 256 * c);
+                    v[c] = ob_m[c] ? own : v[c];
+                }
                 if (decltype(xedge)::value && dx == 1) v[c] = ob_p[c] ? surr(k) : v[c];
                 if (XMODE != XMODE_PERIODIC && dy == 1) v[c] = ob_u ? surr(k) : v[c];
             }
             a[k] = L::make(v);
         }
     };
-    auto to_lds = [&](auto ph, const V* a, const bool* blocked) {
-        constexpr int SWR = decltype(ph)::value * C::ROWB;
+    auto to_lds = [&](auto xedge, auto ph, int q, const V* a, const bool* blocked) {
+        constexpr int PH = decltype(ph)::value;
+        if (XMODE != XMODE_PERIODIC && q == qhi) {
+            // phantom row below the last domain row (wave-uniform, once per chunk at most): the
+            // next level pulls its dy = -1 populations of row N-1 from here with the usual
+            // column shift and must find row N-1's own values
+#pragma unroll
+            for (int sl = 0; sl < 3; sl++) {
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    const float v = *reinterpret_cast<const float*>(
+                        wr_base + C::slot_off(sl, PH, 1) + 4 * (sl - 1) + 256 * c);
+                    *reinterpret_cast<float*>(wr_base + C::slot_off(sl, PH, 0) + 256 * c) = v;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < Q; k++) {
 #pragma unroll
             for (int c = 0; c < CPL; c++)
-                *reinterpret_cast<float*>(wr_base + SWR + slot_of(k) * C::RW * 4 + 256 * c) = L::get(a[k], c);
+                *reinterpret_cast<float*>(wr_base + C::slot_off(slot_of(k), PH, 0) + 256 * c) = L::get(a[k], c);
         }
 #pragma unroll
-        for (int c = 0; c < CPL; c++) wr_flag[SWR + 64 * c] = blocked[c];
+        for (int c = 0; c < CPL; c++) wr_flag[C::flag_off(PH, 0) + 64 * c] = blocked[c];
+        if (decltype(xedge)::value) {
+#pragma unroll
+            for (int k = 0; k < Q; k++) {
+                if (slot_of(k) != 0) continue;
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                    if (last_col[c]) *reinterpret_cast<float*>(wr_lev + C::edge_off(PH, 0)) = L::get(a[k], c);
+            }
+        }
     };
 
     auto run = [&](auto xedge) {
@@ -294,7 +374,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
                 load_row(xedge, q + PF, pr, mw);
                 reflect_v(a, blocked);
                 collide_v(a, blocked, omega);
-                to_lds(ph, a, blocked);
+                to_lds(xedge, ph, q, a, blocked);
                 q += 1;
                 __syncthreads();
             };
@@ -313,7 +393,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
                 reflect_v(a, blocked);
                 collide_v(a, blocked, omega);
                 if (s < T) {
-                    to_lds(ph, a, blocked);
+                    to_lds(xedge, ph, q, a, blocked);
                 } else {
                     const bool in = q >= rlo && q < rhi;
                     if (in) {
@@ -406,6 +486,8 @@ hipError_t launch_step_tb(const void* gin, void* gout, const uint64_t* mask, con
         case 2: launch_tb_T<2, LBM_TB_NB2, LBM_TB_CPL2, LBM_TB_MARG2>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
         case 3: launch_tb_T<3, LBM_TB_NB3, LBM_TB_CPL3, LBM_TB_MARG3>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
         case 4: launch_tb_T<4, LBM_TB_NB4, LBM_TB_CPL4, LBM_TB_MARG4>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
+        case 5: launch_tb_T<5, LBM_TB_NB5, LBM_TB_CPL5, LBM_TB_MARG5>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
+        case 6: launch_tb_T<6, LBM_TB_NB6, LBM_TB_CPL6, LBM_TB_MARG6>(gin, gout, mask, geo, xmode, half, row0, nrows, Ry, st); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -50,7 +50,7 @@ OUTPUT_INTERVAL = 201     # latticeboltzmann.py:72
 # latticeboltzmann.py:55-71 has RTX_2070 / RTX_3090 / A100_80GB; the MI355X presets only choose
 # INNER_TIMESTEPS (launch geometry is the library's business).
 TUNINGS = {
-    "MI355X": {"INNER_TIMESTEPS": 3},     # LDS temporal blocking
+    "MI355X": {"INNER_TIMESTEPS": 6},     # LDS temporal blocking, one launch per 6 updates
     "MI355X_T1": {"INNER_TIMESTEPS": 1},  # one update per launch (pure bandwidth)
 }
 

@@ -11,7 +11,7 @@ from oracle import lbm_ref as oc
 pytestmark = pytest.mark.gpu
 
 
-def _run_case(N, M, T, boundary, tb_rows, n_outer=3, omega=0.3, seed=0, density=0.08, tb_max=4):
+def _run_case(N, M, T, boundary, tb_rows, n_outer=3, omega=0.3, seed=0, density=0.08, tb_max=6):
     from latticeboltzmann_amd.lb_hip_kernel import Solver
     rng = np.random.default_rng(seed + N * 131 + M)
     blocked = rng.random((N, M)) < density
@@ -38,18 +38,19 @@ def _run_case(N, M, T, boundary, tb_rows, n_outer=3, omega=0.3, seed=0, density=
 
 
 @pytest.mark.parametrize("boundary", ["reference", "periodic"])
-@pytest.mark.parametrize("T", [2, 3, 4])
+@pytest.mark.parametrize("T", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("shape,tb_rows", [((40, 300), 16), ((37, 130), 256), ((64, 512), 7),
                                            ((9, 64), 3), ((50, 257), 20), ((21, 8), 5)])
 def test_tb_small(boundary, T, shape, tb_rows):
-    _run_case(shape[0], shape[1], T, boundary, tb_rows)
+    _run_case(shape[0], shape[1], T, boundary, tb_rows, tb_max=6)  # one launch of depth T
 
 
-@pytest.mark.parametrize("T", [5, 6])
-def test_tb_split_depths(T):
-    """inner_timesteps beyond the deepest launch are split into balanced launches (5=3+2, 6=3+3)."""
-    _run_case(48, 320, T, "reference", 16, n_outer=2)
-    _run_case(48, 320, T, "periodic", 16, n_outer=2)
+@pytest.mark.parametrize("T,tb_max", [(5, 4), (6, 4), (7, 6), (9, 6), (5, 2), (3, 1)])
+def test_tb_split_depths(T, tb_max):
+    """inner_timesteps beyond the deepest launch in use are split into balanced launches
+    (cap 4: 5=3+2, 6=3+3; cap 6: 7=4+3, 9=5+4; cap 2: 5=2+2+1; cap 1: the T=1 kernel only)."""
+    _run_case(48, 320, T, "reference", 16, n_outer=2, tb_max=tb_max)
+    _run_case(48, 320, T, "periodic", 16, n_outer=2, tb_max=tb_max)
 
 
 def test_tb_cylinder():

@@ -11,10 +11,11 @@ def main():
     boundary = sys.argv[4] if len(sys.argv) > 4 else "periodic"
     T = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     tb_rows = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    tb_max = int(sys.argv[7]) if len(sys.argv) > 7 else 6
     s = Solver(N, M, 1e-14, inner_timesteps=T, boundary=boundary)
     from oracle import lbm_numpy as onp
     s.set_surroundings(onp.ambient())
-    s.set_tuning(4, tb_rows)
+    s.set_tuning(tb_max, tb_rows)
     s.init_equilibrium(100.0, (0.0, 0.1), amp=0.01, seed=0)
     s.fused_collide_stream(3)
     s.sync()
