@@ -137,6 +137,23 @@ __global__ __launch_bounds__(256) void kvar(const float* __restrict__ gin, float
     do_tile<FLAGS>(gin, gout, mask, geo, y, xb, lane);
 }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+// pure streaming copies of the same 9.66 GB buffer: what the memory system gives a kernel that does
+// nothing else (the yardstick for the fused kernel's 72 B/update)
+__global__ __launch_bounds__(256) void copy4(const v4f* __restrict__ in, v4f* __restrict__ out, long long n4) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) __builtin_nontemporal_store(in[i], out + i);
+}
+__global__ __launch_bounds__(256) void copy1(const float* __restrict__ in, float* __restrict__ out, long long n) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(in[i], out + i);
+}
+__global__ __launch_bounds__(256) void copy4p(const v4f* __restrict__ in, v4f* __restrict__ out, long long n4) {
+    // persistent grid-stride
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+        __builtin_nontemporal_store(in[i], out + i);
+}
+
 __global__ void initk(float* f, Geom geo) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long n = (long long)geo.N * geo.rowStride;
@@ -169,7 +186,7 @@ int main(int argc, char** argv) {
         mk<0>("base"), mk<F_NT_ST>("nt_store"), mk<F_NT_ST | F_NT_LD>("nt_both"), mk<F_NT_LD>("nt_load"),
         mk<F_NO_REMAP>("no_remap"), mk<F_ROWS4>("rows4"), mk<F_ROWS4 | F_NT_ST>("rows4_ntst"),
         mk<F_TWO | F_NT_ST>("two_rows_ntst"), mk<F_PK | F_NT_ST>("pk_cols_ntst"), mk<F_PKROW | F_NT_ST>("pk_rows_ntst"),
-        mk<F_PK>("pk_cols"), mk<F_PK | F_NT_ST | F_NT_LD>("pk_cols_ntboth"),
+        mk<F_PK>("pk_cols"),
     };
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<std::vector<float>> ms(vars.size());
@@ -185,6 +202,27 @@ int main(int argc, char** argv) {
             CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
             float t; CHECK(hipEventElapsedTime(&t, e0, e1));
             if (r > 0) ms[v].push_back(t / reps);
+        }
+    }
+    {
+        const long long n = (long long)N * geo.rowStride;
+        for (int mode = 0; mode < 4; mode++) {
+            std::vector<float> t;
+            for (int r = 0; r < rounds + 1; r++) {
+                CHECK(hipEventRecord(e0, 0));
+                for (int i = 0; i < reps; i++) {
+                    if (mode == 0) hipLaunchKernelGGL(copy4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, 0, (const v4f*)a, (v4f*)b, n / 4);
+                    else if (mode == 1) hipLaunchKernelGGL(copy1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const float*)a, b, n);
+                    else if (mode == 2) hipLaunchKernelGGL(copy4p, dim3(256 * 16), dim3(256), 0, 0, (const v4f*)a, (v4f*)b, n / 4);
+                    else CHECK(hipMemcpyAsync(b, a, n * 4, hipMemcpyDeviceToDevice, 0));
+                }
+                CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+                float ms1; CHECK(hipEventElapsedTime(&ms1, e0, e1));
+                if (r > 0) t.push_back(ms1 / reps);
+            }
+            std::sort(t.begin(), t.end());
+            const char* nm[4] = {"copy float4", "copy float", "copy float4 persistent", "hipMemcpy D2D"};
+            printf("%-24s median %.3f ms  %.3f TB/s (read + write)\n", nm[mode], t[t.size() / 2], 2.0 * n * 4 / t[t.size() / 2] / 1e9);
         }
     }
     float chk[4]; CHECK(hipMemcpy(chk, a + 12345 * 64, sizeof chk, hipMemcpyDeviceToHost));
