@@ -221,7 +221,7 @@ class Solver:
             assert frame.shape == (self.N, self.M, 3), frame.shape
         _check(self._L.lbm_fused_collide_stream_display(self._h, _bptr(frame)))
 
-    def set_tuning(self, tb_max_depth=6, tb_rows=0):
+    def set_tuning(self, tb_max_depth=0, tb_rows=0):
         _check(self._L.lbm_set_tuning(self._h, tb_max_depth, tb_rows))
 
     def step_rows(self, row0, nrows, finish):
