@@ -27,10 +27,12 @@ def slab_rows(global_rows, world, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def neighbours(world, rank, boundary):
-    """(up, down) ranks across the top / bottom seam, None at a true domain edge."""
+def neighbours(world, rank, boundary, self_seam=False):
+    """(up, down) ranks across the top / bottom seam, None at a true domain edge.  self_seam: a
+    single periodic rank treats its own wrap-around as a seam and exchanges halos with itself
+    (exercises the whole schedule, RCCL included, on one GPU)."""
     if world == 1:
-        return None, None
+        return (0, 0) if self_seam and boundary == "periodic" else (None, None)
     if boundary == "periodic":
         return (rank - 1) % world, (rank + 1) % world
     return (rank - 1 if rank > 0 else None), (rank + 1 if rank < world - 1 else None)
@@ -91,7 +93,7 @@ class SlabSolver:
 
     def __init__(self, global_rows, M, omega, rank, world, boundary="periodic", halo=4,
                  dtype=np.float32, device=None, dist=None, group=None, host_staged=None,
-                 tb_max_depth=1):
+                 tb_max_depth=1, self_seam=False):
         import torch
         self.torch = torch
         self.dist = dist
@@ -100,9 +102,10 @@ class SlabSolver:
         self.global_rows, self.M = global_rows, M
         self.row_lo, self.row_hi = slab_rows(global_rows, world, rank)
         self.N = self.row_hi - self.row_lo
-        self.up, self.down = neighbours(world, rank, boundary)
-        self.halo = halo if world > 1 else 0
-        if world > 1 and self.N < 2 * halo:
+        self.up, self.down = neighbours(world, rank, boundary, self_seam)
+        self.seams = self.up is not None or self.down is not None
+        self.halo = halo if self.seams else 0
+        if self.seams and self.N < 2 * halo:
             raise ValueError(f"slab of {self.N} rows is too thin for halo {halo}")
         self.device = torch.cuda.current_device() if device is None else device
         self.solver = hk.Solver(
@@ -119,7 +122,7 @@ class SlabSolver:
         # gloo cannot send/recv device memory: stage the halos through the host (no overlap).
         # Only for rehearsing several ranks on one GPU; RCCL moves device memory directly.
         if host_staged is None:
-            host_staged = world > 1 and dist is not None and dist.get_backend(group) == "gloo"
+            host_staged = self.seams and dist is not None and dist.get_backend(group) == "gloo"
         self.host_staged = host_staged
 
     # -- scene -------------------------------------------------------------------------------------
@@ -161,7 +164,7 @@ class SlabSolver:
 
     def step(self, n=1):
         """Advance by n updates (asynchronous)."""
-        if self.world == 1:
+        if not self.seams:
             self.solver.advance(n)
             return
         advance(self, n)

@@ -112,3 +112,47 @@ def test_two_slabs_with_temporal_blocking(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_worker_tb, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(2))
+
+
+_RCCL_SELF = r"""
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch
+import torch.distributed as dist
+from latticeboltzmann_amd.slabs import SlabSolver
+from oracle import lbm_numpy as onp
+from oracle import lbm_ref as oc
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                        device_id=torch.device("cuda:0"))
+G, M = 192, 320
+rng = np.random.default_rng(21)
+blocked = rng.random((G, M)) < 0.05
+cells = onp.perturbed_cells(G, M, seed=8, amp=0.05)
+surr = onp.ambient()
+slab = SlabSolver(G, M, 0.2, 0, 1, boundary="periodic", halo=4, device=0, dist=dist, self_seam=True)
+assert slab.seams and not slab.host_staged and slab.up == 0 and slab.down == 0
+slab.set_surroundings(surr)
+slab.upload_global(cells, blocked)
+ref = cells.copy()
+for n in (1, 3, 4, 9, 2, 16):
+    slab.step(n)
+    oc.run(ref, blocked, n, 0.2, surr, "periodic")
+    got = slab.read_cells()
+    assert np.array_equal(got, ref), (n, float(np.abs(got - ref).max()))
+slab.close()
+dist.destroy_process_group()
+print("rccl self-seam ok")
+"""
+
+
+def test_rccl_path_with_a_self_seam():
+    """The RCCL data path on the one GPU of the box: a single periodic rank treats its own
+    wrap-around as a seam, so every cycle sends its edge rows to itself through
+    torch.distributed/nccl (device memory handed over directly, communication stream, events,
+    interior update overlapped) — the code the multi-GPU bench runs, bit for bit against the oracle."""
+    import subprocess
+    code = _RCCL_SELF.format(root=ROOT, port=_free_port())
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "rccl self-seam ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
