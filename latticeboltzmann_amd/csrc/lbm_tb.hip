@@ -68,6 +68,9 @@
 #ifndef LBM_TB_MARG6
 #define LBM_TB_MARG6 8
 #endif
+#ifndef LBM_TB_PF
+#define LBM_TB_PF 2
+#endif
 #ifndef LBM_TB_STORE
 #define LBM_TB_STORE st
 #endif
@@ -146,7 +149,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     using C = TB<T, NB, CPL, MARG>;
     using L = LaneV<CPL>;
     using V = typename L::V;
-    constexpr int PF = 2;  // stage-1 rows in flight
+    constexpr int PF = LBM_TB_PF;  // stage-1 rows in flight (1, 2 or 4: divides the unroll)
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDSB];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -380,9 +383,9 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
             };
             for (int i = 0; i < nit; i += 4) {
                 it(std::integral_constant<int, 0>{}, pre[0], pmw[0]);
-                it(std::integral_constant<int, 1>{}, pre[1], pmw[1]);
-                it(std::integral_constant<int, 2>{}, pre[0], pmw[0]);
-                it(std::integral_constant<int, 3>{}, pre[1], pmw[1]);
+                it(std::integral_constant<int, 1>{}, pre[1 % PF], pmw[1 % PF]);
+                it(std::integral_constant<int, 2>{}, pre[2 % PF], pmw[2 % PF]);
+                it(std::integral_constant<int, 3>{}, pre[3 % PF], pmw[3 % PF]);
             }
         } else {
             ST* orow = gout + (long long)(wrap_row(clampr(q)) + G) * RS;
