@@ -94,7 +94,9 @@ int lbm_set_stream(lbm_solver* s, void* hip_stream);
 
 /* --- upload: replaces drv.to_device(cells / blocked / surroundings), latticeboltzmann.py:147-150.
  * Host pointers; the library copies, the caller keeps ownership.  Rows [row0, row0+nrows) in
- * solver-local coordinates; ghost rows are addressed as -halo..-1 and N..N+halo-1. ----------- */
+ * solver-local coordinates; ghost rows are addressed as -halo..-1 and N..N+halo-1.  Before the
+ * first step cells may be uploaded in pieces; once the solver has stepped, an upload is a new
+ * initial condition and must cover all N rows (it resets the step count). -------------------- */
 int lbm_set_surroundings(lbm_solver* s, const float surroundings[9]);
 int lbm_upload_blocked(lbm_solver* s, const uint8_t* blocked, int row0, int nrows);
 int lbm_upload_cells(lbm_solver* s, const float* cells, int row0, int nrows);
@@ -142,7 +144,7 @@ int lbm_steps_done(lbm_solver* s, int64_t* steps);
 /* --- readback (new capability named by the north star: density / velocity for rendering; the
  * reference only reads RGB frames back, latticeboltzmann.py:191).  Synchronous.  Rows
  * [row0,row0+nrows) x columns [col0,col0+ncols); outputs are dense windows in the conventions
- * above.  Any output pointer may be NULL. ---------------------------------------------------- */
+ * above.  Of rho and u one may be NULL. ------------------------------------------------------ */
 int lbm_read_cells(lbm_solver* s, float* cells, int row0, int nrows, int col0, int ncols);
 int lbm_read_moments(lbm_solver* s, float* rho, float* u, int row0, int nrows, int col0, int ncols);
 int lbm_read_blocked(lbm_solver* s, uint8_t* blocked, int row0, int nrows);

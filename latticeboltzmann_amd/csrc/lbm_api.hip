@@ -213,6 +213,10 @@ int lbm_upload_cells(lbm_solver* s, const float* cells, int row0, int nrows) {
     int rc = check_rows(s, row0, nrows, true);
     if (rc) return rc;
     if (s->pulled) {  // a new initial condition: back to the freshly-uploaded state
+        // the buffer holds post-collision populations now; a partial upload would mix the two
+        if (row0 > 0 || row0 + nrows < s->geo.N)
+            return fail(LBM_ERR_INVALID, "after stepping, an upload must cover all %d rows (got [%d, %d))",
+                        s->geo.N, row0, row0 + nrows);
         s->pulled = false;
         s->steps = 0;
     }
@@ -438,6 +442,7 @@ static int observe(lbm_solver* s, int row0, int nrows, int col0, int ncols, floa
 
 int lbm_read_cells(lbm_solver* s, float* cells, int row0, int nrows, int col0, int ncols) {
     ENTER(s);
+    if (!cells) return fail(LBM_ERR_INVALID, "cells is null");
     int rc = check_window(s, row0, nrows, col0, ncols);
     if (rc) return rc;
     return observe(s, row0, nrows, col0, ncols, cells, nullptr, nullptr, nullptr);
@@ -445,6 +450,7 @@ int lbm_read_cells(lbm_solver* s, float* cells, int row0, int nrows, int col0, i
 
 int lbm_read_moments(lbm_solver* s, float* rho, float* u, int row0, int nrows, int col0, int ncols) {
     ENTER(s);
+    if (!rho && !u) return fail(LBM_ERR_INVALID, "rho and u are both null");
     int rc = check_window(s, row0, nrows, col0, ncols);
     if (rc) return rc;
     return observe(s, row0, nrows, col0, ncols, nullptr, rho, u, nullptr);

@@ -156,3 +156,37 @@ def test_extreme_magnitudes_take_the_exact_division_path(T):
             bad = np.argwhere(~((got == ref) | (np.isnan(got) & np.isnan(ref))))
             assert bad.size == 0, f"T={T}: {len(bad)} mismatches, first {bad[:5].tolist()}"
     s.close()
+
+
+def test_error_behaviour_of_the_abi():
+    """Nonzero status -> RuntimeError with lbm_last_error() (the analogue of pycuda raising):
+    bad windows, null outputs, a partial upload after stepping, tuning out of range."""
+    import ctypes
+    from latticeboltzmann_amd import lb_hip_kernel as hk
+    s = hk.Solver(24, 100, 0.3)
+    s.set_surroundings(onp.ambient())
+    cells = onp.perturbed_cells(24, 100, seed=1)
+    s.upload_cells(cells[:10], 0)       # piecewise before the first step is fine
+    s.upload_cells(cells[10:], 10)
+    s.fused_collide_stream(2)
+    with pytest.raises(RuntimeError, match="must cover all"):
+        s.upload_cells(cells[:10], 0)
+    with pytest.raises(RuntimeError, match="outside"):
+        s.read_cells(rows=(0, 25))
+    with pytest.raises(RuntimeError, match="columns"):
+        s.read_moments(cols=(90, 101))
+    with pytest.raises(RuntimeError, match="tb_max_depth"):
+        s.set_tuning(7, 0)
+    L = hk.load_library()
+    assert L.lbm_read_cells(s._h, None, 0, 1, 0, 1) != 0 and b"null" in L.lbm_last_error()
+    assert L.lbm_read_moments(s._h, None, None, 0, 1, 0, 1) != 0
+    assert L.lbm_fused_collide_stream(s._h, -1) != 0
+    assert L.lbm_fused_collide_stream(None, 1) != 0 and b"null solver" in L.lbm_last_error()
+    # the solver is still usable and correct after the rejected calls
+    ref = oc.run(cells.copy(), np.zeros((24, 100), bool), 2, 0.3, onp.ambient())
+    assert np.array_equal(s.read_cells(), ref)
+    s.upload_cells(cells)               # a full upload restarts
+    assert s.steps_done == 0
+    s.close()
+    with pytest.raises(RuntimeError):   # a second solver with an absurd size: NOMEM, not a crash
+        hk.Solver(1 << 20, 1 << 20, 0.3)
