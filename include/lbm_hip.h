@@ -150,6 +150,11 @@ int lbm_read_moments(lbm_solver* s, float* rho, float* u, int row0, int nrows, i
 int lbm_read_blocked(lbm_solver* s, uint8_t* blocked, int row0, int nrows);
 /* Render rows [row0,row0+nrows) as RGB uint8 (nrows, M, 3), lb_cuda_kernel.cu:308-319. */
 int lbm_render(lbm_solver* s, uint8_t* rgb, int row0, int nrows);
+/* Page-locked host memory (replaces drv.pagelocked_empty for frame1 / frame2,
+ * latticeboltzmann.py:158-159), so that the frame copy of lbm_fused_collide_stream_display is a
+ * true asynchronous DMA and stepping continues under it. */
+int lbm_host_alloc(size_t bytes, void** host_ptr);
+int lbm_host_free(void* host_ptr);
 
 /* --- y-slab halo exchange (no reference code exists, only README.md:12).  The
  * library exposes device pointers; the exchange itself (RCCL send/recv) belongs to the caller.

@@ -481,6 +481,19 @@ int lbm_render(lbm_solver* s, uint8_t* rgb, int row0, int nrows) {
     return observe(s, row0, nrows, 0, s->geo.M, nullptr, nullptr, nullptr, rgb);
 }
 
+int lbm_host_alloc(size_t bytes, void** host_ptr) {
+    if (!host_ptr || bytes == 0) return fail(LBM_ERR_INVALID, "bad argument");
+    *host_ptr = nullptr;
+    HIPCHK(hipHostMalloc(host_ptr, bytes, hipHostMallocDefault));
+    return LBM_OK;
+}
+
+int lbm_host_free(void* host_ptr) {
+    if (!host_ptr) return LBM_OK;
+    HIPCHK(hipHostFree(host_ptr));
+    return LBM_OK;
+}
+
 int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame) {
     ENTER(s);
     int rc = lbm_fused_collide_stream(s, 1);

@@ -105,7 +105,7 @@ class Simulation:
         self.solver.upload_blocked(self.blocked)
         self.solver.upload_cells(np.ascontiguousarray(cells))
         # two host frames, as the pinned frame1 / frame2 of latticeboltzmann.py:158-159
-        self.frames = [np.empty((self.N, self.M, 3), np.uint8) for _ in range(2)]
+        self.frames = [lb_hip_kernel.pagelocked_empty((self.N, self.M, 3), np.uint8) for _ in range(2)]
         self.curr_iter = 0
 
     # latticeboltzmann.py:186-196: one outer iteration, rendering every OUTPUT_INTERVAL
@@ -126,6 +126,10 @@ class Simulation:
         return self.solver.read_cells(rows, cols)
 
     def close(self):
+        self.solver.sync()
+        for f in self.frames:
+            lb_hip_kernel.release_pagelocked(f)
+        self.frames = []
         self.solver.close()
 
 

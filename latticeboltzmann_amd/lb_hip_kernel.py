@@ -29,8 +29,31 @@ SYMBOLS = [
     "lbm_fused_collide_stream_display", "lbm_step_rows", "lbm_fused_collide_stream_timed",
     "lbm_sync", "lbm_steps_done", "lbm_read_cells", "lbm_read_moments", "lbm_read_blocked",
     "lbm_render", "lbm_halo_region", "lbm_mask_halo_region", "lbm_halo_valid",
-    "lbm_halo_mark_filled", "lbm_set_tuning", "lbm_advance",
+    "lbm_halo_mark_filled", "lbm_set_tuning", "lbm_advance", "lbm_host_alloc",
+    "lbm_host_free",
 ]
+
+
+def pagelocked_empty(shape, dtype=np.uint8):
+    """drv.pagelocked_empty of latticeboltzmann.py:158-159: a numpy array in page-locked host
+    memory (asynchronous device-to-host copies); release_pagelocked frees it."""
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    p = ctypes.c_void_p()
+    _check(load_library().lbm_host_alloc(nbytes, ctypes.byref(p)))
+    buf = (ctypes.c_ubyte * nbytes).from_address(p.value)
+    a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    _PINNED[a.ctypes.data] = p.value
+    return a
+
+
+def release_pagelocked(a):
+    p = _PINNED.pop(a.ctypes.data, None)
+    if p is not None:
+        _check(load_library().lbm_host_free(p))
+
+
+_PINNED = {}
 
 
 class lbm_config(ctypes.Structure):
@@ -99,6 +122,8 @@ def load_library(path=LIB_PATH):
         "lbm_halo_mark_filled": ([H], c_int),
         "lbm_set_tuning": ([H, c_int, c_int], c_int),
         "lbm_advance": ([H, c_int], c_int),
+        "lbm_host_alloc": ([ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)], c_int),
+        "lbm_host_free": ([ctypes.c_void_p], c_int),
     }
     assert set(protos) == set(SYMBOLS)
     for name, (argtypes, restype) in protos.items():
