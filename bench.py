@@ -58,6 +58,17 @@ def cpu_baseline(budget_s=12.0):
            "sample": f"oracle/lbm_numpy.py (numpy {np.__version__}; elementwise single-threaded, "
                      f"BLAS matmul up to {blas_threads} threads), {n}x{n} periodic twin, {steps} steps "
                      f"in {dt:.1f} s; host has {os.cpu_count()} logical CPUs"}
+    # the reference's own default scene size (BASELINE.json configs[0]: 400 x 800 cylinder)
+    cb = onp.blocked_cylinder(400, 800)
+    cc = onp.initial_cells(cb, surr)
+    co = onp.make_omega(cb, onp.OMEGA)
+    onp.step(cc, cb, co, surr, "reference")
+    t0 = time.perf_counter()
+    for _ in range(20):
+        onp.step(cc, cb, co, surr, "reference")
+    dt = time.perf_counter() - t0
+    out["numpy_cylinder"] = {"value": 400 * 800 * 20 / dt / 1e9, "unit": "GLUPS", "cores": blas_threads,
+                             "sample": f"oracle/lbm_numpy.py, 400x800 cylinder scene, 20 steps in {dt:.1f} s"}
     # the C restatement (OpenMP), a fairer CPU figure
     omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, os.cpu_count() or 1)
     csteps = 8
