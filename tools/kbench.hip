@@ -154,6 +154,34 @@ __global__ __launch_bounds__(256) void copy4p(const v4f* __restrict__ in, v4f* _
         __builtin_nontemporal_store(in[i], out + i);
 }
 
+// U float4 loads in flight per thread, then U stores (bursts of reads, then of writes)
+template <int U, int NT>
+__global__ __launch_bounds__(256) void copy4u(const v4f* __restrict__ in, v4f* __restrict__ out, long long n4) {
+    const long long base = (long long)blockIdx.x * (256 * U) + threadIdx.x;
+    v4f v[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+        const long long i = base + j * 256;
+        if (NT & 2) v[j] = __builtin_nontemporal_load(in + (i < n4 ? i : 0));
+        else v[j] = in[i < n4 ? i : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+        const long long i = base + j * 256;
+        if (i < n4) { if (NT & 1) __builtin_nontemporal_store(v[j], out + i); else out[i] = v[j]; }
+    }
+}
+// read-only and write-only sweeps: the two halves of the mix
+__global__ __launch_bounds__(256) void read4(const v4f* __restrict__ in, float* __restrict__ out, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    v4f v = i < n4 ? in[i] : v4f{0, 0, 0, 0};
+    if (v.x == 12345.678f && v.y == -1.0f) out[0] = v.z;  // never true: keeps the load
+}
+__global__ __launch_bounds__(256) void write4(v4f* __restrict__ out, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) __builtin_nontemporal_store(v4f{1.0f, 2.0f, 3.0f, (float)threadIdx.x}, out + i);
+}
+
 __global__ void initk(float* f, Geom geo) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long n = (long long)geo.N * geo.rowStride;
@@ -206,7 +234,7 @@ int main(int argc, char** argv) {
     }
     {
         const long long n = (long long)N * geo.rowStride;
-        for (int mode = 0; mode < 4; mode++) {
+        for (int mode = 0; mode < 10; mode++) {
             std::vector<float> t;
             for (int r = 0; r < rounds + 1; r++) {
                 CHECK(hipEventRecord(e0, 0));
@@ -214,15 +242,24 @@ int main(int argc, char** argv) {
                     if (mode == 0) hipLaunchKernelGGL(copy4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, 0, (const v4f*)a, (v4f*)b, n / 4);
                     else if (mode == 1) hipLaunchKernelGGL(copy1, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const float*)a, b, n);
                     else if (mode == 2) hipLaunchKernelGGL(copy4p, dim3(256 * 16), dim3(256), 0, 0, (const v4f*)a, (v4f*)b, n / 4);
-                    else CHECK(hipMemcpyAsync(b, a, n * 4, hipMemcpyDeviceToDevice, 0));
+                    else if (mode == 3) CHECK(hipMemcpyAsync(b, a, n * 4, hipMemcpyDeviceToDevice, 0));
+                    else if (mode == 4) hipLaunchKernelGGL((copy4u<2, 1>), dim3((unsigned)((n / 4 + 511) / 512)), dim3(256), 0, 0, (const v4f*)a, (v4f*)b, n / 4);
+                    else if (mode == 5) hipLaunchKernelGGL((copy4u<4, 1>), dim3((unsigned)((n / 4 + 1023) / 1024)), dim3(256), 0, 0, (const v4f*)a, (v4f*)b, n / 4);
+                    else if (mode == 6) hipLaunchKernelGGL((copy4u<8, 1>), dim3((unsigned)((n / 4 + 2047) / 2048)), dim3(256), 0, 0, (const v4f*)a, (v4f*)b, n / 4);
+                    else if (mode == 7) hipLaunchKernelGGL((copy4u<4, 3>), dim3((unsigned)((n / 4 + 1023) / 1024)), dim3(256), 0, 0, (const v4f*)a, (v4f*)b, n / 4);
+                    else if (mode == 8) hipLaunchKernelGGL(read4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, 0, (const v4f*)a, b, n / 4);
+                    else hipLaunchKernelGGL(write4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, 0, (v4f*)b, n / 4);
                 }
                 CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
                 float ms1; CHECK(hipEventElapsedTime(&ms1, e0, e1));
                 if (r > 0) t.push_back(ms1 / reps);
             }
             std::sort(t.begin(), t.end());
-            const char* nm[4] = {"copy float4", "copy float", "copy float4 persistent", "hipMemcpy D2D"};
-            printf("%-24s median %.3f ms  %.3f TB/s (read + write)\n", nm[mode], t[t.size() / 2], 2.0 * n * 4 / t[t.size() / 2] / 1e9);
+            const char* nm[10] = {"copy float4", "copy float", "copy float4 persistent", "hipMemcpy D2D",
+                                  "copy float4 x2", "copy float4 x4", "copy float4 x8", "copy float4 x4 nt-load",
+                                  "read-only float4", "write-only float4"};
+            const double vol = mode >= 8 ? 1.0 : 2.0;
+            printf("%-24s median %.3f ms  %.3f TB/s\n", nm[mode], t[t.size() / 2], vol * n * 4 / t[t.size() / 2] / 1e9);
         }
     }
     float chk[4]; CHECK(hipMemcpy(chk, a + 12345 * 64, sizeof chk, hipMemcpyDeviceToHost));
