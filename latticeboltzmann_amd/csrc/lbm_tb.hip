@@ -279,15 +279,27 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         const bool ob_u = r - 1 < qlo;
 #pragma unroll
         for (int k = 0; k < Q; k++) {
-            const int dy = dy_of(k), dx = dx_of(k);
+            const int dx = dx_of(k);
             float v[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
                 v[c] = L::get(a[k], c);
                 if (decltype(xedge)::value && dx == 1) v[c] = ob_p[c] ? surr(k) : v[c];
-                if (dy == 1) v[c] = ob_u ? surr(k) : v[c];
             }
             a[k] = L::make(v);
+        }
+        // top inlet: a wave-uniform, rare branch (row 0 only) rather than selects in every row, so
+        // that the ambient values need no registers in the row loop (a spilled scalar would be
+        // reloaded there by a vmem load whose in-order vmcnt wait drains the stage-1 prefetch)
+        if (ob_u) {
+#pragma unroll
+            for (int k = 0; k < Q; k++) {
+                if (dy_of(k) != 1) continue;
+                float v[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; c++) v[c] = surr(k);
+                a[k] = L::make(v);
+            }
         }
     };
     // stages 2..T, iteration phase PH = i & 3: gather the pulled populations of row r and the
@@ -316,9 +328,18 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
                     v[c] = ob_m[c] ? own : v[c];
                 }
                 if (decltype(xedge)::value && dx == 1) v[c] = ob_p[c] ? surr(k) : v[c];
-                if (XMODE != XMODE_PERIODIC && dy == 1) v[c] = ob_u ? surr(k) : v[c];
             }
             a[k] = L::make(v);
+        }
+        if (ob_u) {  // top inlet, wave-uniform and rare (see inlet_fix)
+#pragma unroll
+            for (int k = 0; k < Q; k++) {
+                if (dy_of(k) != 1) continue;
+                float v[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; c++) v[c] = surr(k);
+                a[k] = L::make(v);
+            }
         }
     };
     auto to_lds = [&](auto xedge, auto ph, int q, const V* a, const bool* blocked) {
