@@ -32,7 +32,7 @@
 
 // Window width (NB 64-column blocks), cells per
 // lane and margin for each launch depth, from sweeps on MI355X at 16384 x 16384 (periodic /
-// reference edges): T=2 143 / 144, T=3 213 / 184, T=4 249 / 212, T=5 241 / 202, T=6 274 / 224 GLUPS.
+// reference edges): T=2 143 / 146, T=3 213 / 210, T=4 249 / 237, T=5 241 / 222, T=6 274 / 253 GLUPS.
 #ifndef LBM_TB_NB2
 #define LBM_TB_NB2 12
 #define LBM_TB_CPL2 2
