@@ -74,7 +74,7 @@ def test_device_memory_wraps_as_torch_tensor():
     s.close()
 
 
-def _worker_tb(rank, world, port, outdir):
+def _worker_tb(rank, world, port, boundary, outdir):
     """Slabs with LDS temporal blocking inside a cycle (halo 6, launches up to 3 deep)."""
     sys.path.insert(0, ROOT)
     import torch
@@ -91,14 +91,14 @@ def _worker_tb(rank, world, port, outdir):
         blocked = rng.random((G, M)) < 0.05
         cells = onp.perturbed_cells(G, M, seed=6, amp=0.05)
         surr = onp.ambient()
-        slab = SlabSolver(G, M, 0.2, rank, world, boundary="periodic", halo=6, device=0, dist=dist,
+        slab = SlabSolver(G, M, 0.2, rank, world, boundary=boundary, halo=6, device=0, dist=dist,
                           tb_max_depth=3)
         slab.set_surroundings(surr)
         slab.upload_global(cells, blocked)
         ref = cells.copy()
         for n in (7, 12, 5):
             slab.step(n)
-            oc.run(ref, blocked, n, 0.2, surr, "periodic")
+            oc.run(ref, blocked, n, 0.2, surr, boundary)
             got = slab.read_cells()
             want = ref[slab.row_lo:slab.row_hi]
             assert np.array_equal(got, want), (rank, n, np.abs(got - want).max())
@@ -108,9 +108,12 @@ def _worker_tb(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
-def test_two_slabs_with_temporal_blocking(tmp_path):
+@pytest.mark.parametrize("boundary", ["periodic", "reference"])
+def test_two_slabs_with_temporal_blocking(tmp_path, boundary):
+    """reference: the top rank has the inlet row and a seam below, the bottom rank a seam above
+    and the outflow row (phantom row of the LDS kernel) below."""
     import torch.multiprocessing as mp
-    mp.spawn(_worker_tb, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker_tb, args=(2, _free_port(), boundary, str(tmp_path)), nprocs=2, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(2))
 
 
