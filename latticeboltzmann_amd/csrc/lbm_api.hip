@@ -24,6 +24,7 @@ static int fail(int code, const char* fmt, ...) {
 #define HIPCHK(expr)                                                                        \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) (void)hipGetLastError(); /* un-stick it for later launch checks */ \
         if (e_ != hipSuccess)                                                               \
             return fail(e_ == hipErrorOutOfMemory ? LBM_ERR_NOMEM : LBM_ERR_HIP,            \
                         "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
@@ -130,6 +131,7 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
 
     int rc = LBM_OK;
     auto bail = [&](hipError_t e, const char* what) {
+        (void)hipGetLastError();  // HIP keeps the last error until it is read: do not leave it behind
         rc = fail(e == hipErrorOutOfMemory ? LBM_ERR_NOMEM : LBM_ERR_HIP, "%s failed: %s", what,
                   hipGetErrorString(e));
     };

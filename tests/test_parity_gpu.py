@@ -190,3 +190,10 @@ def test_error_behaviour_of_the_abi():
     s.close()
     with pytest.raises(RuntimeError):   # a second solver with an absurd size: NOMEM, not a crash
         hk.Solver(1 << 20, 1 << 20, 0.3)
+    # ... and the failed allocation leaves no stale HIP error behind for the next solver
+    s2 = hk.Solver(8, 64, 0.3)
+    s2.upload_blocked(np.zeros((8, 64), bool))
+    s2.upload_cells(onp.perturbed_cells(8, 64, seed=2))
+    s2.fused_collide_stream(2)
+    assert np.isfinite(s2.read_cells()).all()
+    s2.close()
