@@ -58,6 +58,9 @@ static const size_t STAGING_BYTES = 256ull << 20;
 static int check(lbm_solver* s) {
     if (!s) return fail(LBM_ERR_INVALID, "null solver handle");
     HIPCHK(hipSetDevice(s->cfg.device));
+    // HIP's last error is sticky and thread-wide: one left behind by other code in the process
+    // (torch, another library) must not be reported by this call's launch checks
+    (void)hipGetLastError();
     return LBM_OK;
 }
 #define ENTER(s)                      \
