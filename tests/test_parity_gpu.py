@@ -33,7 +33,7 @@ def _compare(s, ref_cells, exact=True):
 
 
 @pytest.mark.parametrize("boundary", ["reference", "periodic"])
-@pytest.mark.parametrize("shape", [(37, 130), (64, 64), (5, 2), (33, 200), (2, 65)])
+@pytest.mark.parametrize("shape", [(37, 130), (64, 64), (5, 2), (33, 200), (2, 65), (1, 64), (1, 2), (3, 129)])
 def test_small_random_scene(boundary, shape):
     N, M = shape
     rng = np.random.default_rng(N * 1000 + M)
@@ -50,6 +50,15 @@ def test_small_random_scene(boundary, shape):
         oc.run(ref, blocked, n, 0.3, onp.ambient(), boundary)
         assert s.steps_done == done
         _compare(s, ref)
+    # ragged and empty windows
+    assert s.read_cells(rows=(0, 0)).shape == (0, M, 9)
+    assert s.read_cells(cols=(M - 1, M - 1)).shape == (N, 0, 9)
+    assert np.array_equal(s.read_cells(rows=(N - 1, N), cols=(M - 1, M)), ref[N - 1:, M - 1:])
+    u, rho = s.read_moments(rows=(0, 1), cols=(0, min(M, 3)))
+    ur, rr = onp.moments(ref[:1, :min(M, 3)])
+    assert np.array_equal(rho, rr) and np.array_equal(u, ur)
+    s.fused_collide_stream(0)  # zero iterations: a no-op
+    assert s.steps_done == done
     s.close()
 
 
