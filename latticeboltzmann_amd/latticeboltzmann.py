@@ -133,6 +133,39 @@ class Simulation:
         self.solver.close()
 
 
+def _hsv_to_rgb(hsv):
+    """matplotlib.colors.hsv_to_rgb when matplotlib is installed (the reference's choice), else the
+    same piecewise formula in numpy."""
+    try:
+        import matplotlib.colors
+        return matplotlib.colors.hsv_to_rgb(hsv)
+    except ImportError:
+        h, s, v = hsv[..., 0], hsv[..., 1], hsv[..., 2]
+        i = (h * 6.0).astype(int)
+        f = h * 6.0 - i
+        p, q, t = v * (1 - s), v * (1 - s * f), v * (1 - s * (1 - f))
+        i = i % 6
+        sel = [i == k for k in range(6)]
+        r = np.select(sel, [v, q, p, p, t, v])
+        g = np.select(sel, [t, v, v, q, p, p])
+        b = np.select(sel, [p, p, t, v, v, q])
+        return np.stack([r, g, b], -1)
+
+
+def display(u, p, video=None):
+    """The host-side frame of the numpy path (latticeboltzmann.py:101-105): hue = flow direction,
+    saturation = 100000 |u|, value = density, clipped to [0, 1].  (The device renderer,
+    lbm_render / lbm_fused_collide_stream_display, follows the CUDA kernel's variant instead:
+    lb_cuda_kernel.cu:308-319.)  Returns the uint8 (N, M, 3) frame and appends it to `video`."""
+    h = (np.arctan2(u[..., 0], u[..., 1]) + math.pi) / 2 / math.pi
+    s = np.sum(u ** 2, axis=-1) ** 0.5 * 100000
+    v = p
+    frame = (_hsv_to_rgb(np.clip(np.stack([h, s, v], 2), 0, 1)) * 255.99).astype(np.uint8)
+    if video is not None:
+        video.append_data(frame)
+    return frame
+
+
 def stats_line(N, M, inner_timesteps, dt, curr_iter):
     """The reference's 1000-iteration line (latticeboltzmann.py:176), same arithmetic."""
     return (f"{dt * 1000 / inner_timesteps} us per iteration /  "
