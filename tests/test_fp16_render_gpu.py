@@ -53,6 +53,39 @@ def test_fp16_storage_is_bit_exact_against_its_emulation():
     s.close()
 
 
+def emulate_fp16_launches(cells, blocked, depths, omega, surr, boundary):
+    """fp16 storage with LDS temporal blocking: the state is rounded to fp16 only where a launch
+    stores it; the time levels inside a launch stay fp32 in LDS.  depths = updates per launch
+    after the initial collide-only launch."""
+    h = r16(oc.collide(r16(cells), blocked, omega))
+    for d in depths:
+        g = h
+        for _ in range(d):
+            g = oc.collide(oc.stream_reflect(g, blocked, surr, boundary), blocked, omega)
+        h = r16(g)
+    return oc.stream_reflect(h, blocked, surr, boundary)
+
+
+@pytest.mark.parametrize("boundary", ["reference", "periodic"])
+def test_fp16_storage_with_temporal_blocking_is_bit_exact_against_its_emulation(boundary):
+    from latticeboltzmann_amd.lb_hip_kernel import Solver
+    N, M = 96, 200
+    blocked = cavity_scene(N, M)
+    surr = onp.ambient()
+    cells = onp.perturbed_cells(N, M, seed=2, amp=0.02)
+    for T, cap, depths in [(3, 3, [2, 3, 3]), (6, 6, [5, 6]), (4, 2, [2, 1, 2, 2])]:
+        s = Solver(N, M, 0.2, inner_timesteps=T, boundary=boundary, dtype=np.float16)
+        s.set_tuning(cap, 0)
+        s.set_surroundings(surr)
+        s.upload_blocked(blocked)
+        s.upload_cells(cells)
+        s.fused_collide_stream((1 + sum(depths)) // T)
+        assert s.steps_done == 1 + sum(depths)
+        want = emulate_fp16_launches(cells, blocked, depths, 0.2, surr, boundary)
+        assert np.array_equal(s.read_cells(), want), (T, cap, boundary)
+        s.close()
+
+
 @pytest.mark.parametrize("T", [1, 3])
 def test_fp16_cavity_within_1e2_of_fp32(T):
     """BASELINE config 5, tolerance 1e-2 (latticeboltzmann.py:18-19: rtol of the fp16 build).
