@@ -85,3 +85,15 @@ def test_tb_equals_t1_on_large_periodic():
         s.close()
     assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3])
     assert np.isfinite(outs[0]).all()
+
+
+def test_random_soak():
+    """tools/stress_parity.py: 300 random (shape, depth, launch cap, chunk rows, edge rule, omega,
+    obstacle density, ambient flow) cases against the oracle, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_parity.py"), "300", "7"],
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "300 cases, 0 mismatching" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
