@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--rows", type=int, default=16384, help="rows per GPU")
     ap.add_argument("--cols", type=int, default=16384)
     ap.add_argument("--halo", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=1,
+                    help="N > 1 only: deepest LDS launch inside a halo cycle (1 = the headline kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -188,7 +190,7 @@ def main():
                 "workload": f"{rows}x{cols} periodic, fp16 storage / fp32 compute, T=1"}
     else:
         slab = SlabSolver(rows * world, cols, onp.OMEGA, rank, world, boundary="periodic",
-                          halo=args.halo, device=local_rank, dist=dist)
+                          halo=args.halo, device=local_rank, dist=dist, tb_max_depth=args.depth)
         slab.set_surroundings(surr)
         slab.init_device_scene(100.0, (0.0, 0.1), amp=0.01, seed=0)
         slab.step(args.warmup)
@@ -230,7 +232,8 @@ def main():
                                    f"INNER_TIMESTEPS=1 (BASELINE.json configs[1])",
                        "rows_per_gpu": rows, "cols": cols, "inner_timesteps": 1,
                        "decomposition": "single domain" if world == 1 else
-                                        f"{world} y-slabs, halo {args.halo}, RCCL send/recv every {args.halo} steps"},
+                                        f"{world} y-slabs, halo {args.halo}, RCCL send/recv every {args.halo} steps"
+                                        + (f", LDS launches up to {args.depth} deep" if args.depth > 1 else "")},
             "frac_of_hbm_roofline": glups * BYTES_PER_UPDATE / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
