@@ -13,7 +13,7 @@ using namespace lbm;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { F_NT_ST = 1, F_NT_LD = 2, F_NO_REMAP = 4, F_ROWS4 = 8, F_PERSIST = 16, F_TWO = 32, F_PK = 64, F_PKROW = 128 };
+enum { F_NT_ST = 1, F_NT_LD = 2, F_NO_REMAP = 4, F_ROWS4 = 8, F_PERSIST = 16, F_TWO = 32, F_PK = 64, F_PKROW = 128, F_ROWXCD = 256, F_ROWXCD2 = 512 };
 
 template <int FLAGS>
 __device__ __forceinline__ float ldx(const float* p) {
@@ -126,7 +126,16 @@ __global__ __launch_bounds__(256) void kvar(const float* __restrict__ gin, float
         return;
     }
     int y, xb;
-    if (FLAGS & F_ROWS4) {
+    if (FLAGS & (F_ROWXCD | F_ROWXCD2)) {
+        // XCD x takes whole rows (F_ROWXCD: rows = x mod 8; F_ROWXCD2: pairs of rows), so that all
+        // XCDs sweep the same few rows at a time: a globally sequential footprint
+        const unsigned b = blockIdx.x, xcd = b & 7u, idx = b >> 3;
+        const unsigned wpr = geo.Mb / 4;  // workgroups per row
+        const unsigned RPX = (FLAGS & F_ROWXCD2) ? 2 : 1;
+        const unsigned grp = idx / (wpr * RPX), rem = idx % (wpr * RPX);
+        y = (int)((grp * 8 + xcd) * RPX + rem / wpr);
+        xb = (int)(rem % wpr) * 4 + wave;
+    } else if (FLAGS & F_ROWS4) {
         // workgroup = 4 rows x 1 xb
         const long long t = wg;  // over (N/4) x Mb
         y = 4 * (int)(t / geo.Mb) + wave; xb = (int)(t % geo.Mb);
@@ -214,7 +223,7 @@ int main(int argc, char** argv) {
         mk<0>("base"), mk<F_NT_ST>("nt_store"), mk<F_NT_ST | F_NT_LD>("nt_both"), mk<F_NT_LD>("nt_load"),
         mk<F_NO_REMAP>("no_remap"), mk<F_ROWS4>("rows4"), mk<F_ROWS4 | F_NT_ST>("rows4_ntst"),
         mk<F_TWO | F_NT_ST>("two_rows_ntst"), mk<F_PK | F_NT_ST>("pk_cols_ntst"), mk<F_PKROW | F_NT_ST>("pk_rows_ntst"),
-        mk<F_PK>("pk_cols"),
+        mk<F_PK>("pk_cols"), mk<F_ROWXCD | F_NT_ST>("rowxcd_ntst"), mk<F_ROWXCD2 | F_NT_ST>("rowxcd2_ntst"),
     };
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<std::vector<float>> ms(vars.size());
