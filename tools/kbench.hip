@@ -211,7 +211,8 @@ int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 16384, M = argc > 2 ? atoi(argv[2]) : 16384;
     const int rounds = argc > 3 ? atoi(argv[3]) : 5, reps = 10;
     Geom geo{};
-    geo.N = N; geo.M = M; geo.Mb = M / 64; geo.G = 0; geo.rowStride = (long long)geo.Mb * CHUNK;
+    geo.N = N; geo.M = M; geo.Mb = M / 64; geo.G = 0; const int padc = argc > 4 ? atoi(argv[4]) : 0;  // extra (unused) chunks per row: row stride experiment
+    geo.rowStride = (long long)(geo.Mb + padc) * CHUNK;
     geo.top = geo.bot = YEDGE_WRAP; geo.omega = 1e-14f;
     const size_t bytes = (size_t)N * geo.rowStride * 4;
     float *a, *b; uint64_t* mask;
