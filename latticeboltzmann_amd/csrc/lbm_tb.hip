@@ -26,6 +26,7 @@
 // clamped to a valid row instead of skipped), so that hipcc can use counted s_waitcnt vmcnt(N) and
 // the stage-1 prefetch really stays in flight across two iterations and barriers.  Only stage 1
 // touches the bit-packed mask; it hands each cell's blocked flag to the later stages through LDS.
+#include <atomic>
 #include <type_traits>
 
 #include "lbm_internal.h"
@@ -473,7 +474,10 @@ static void launch_tb_t(const ST* gin, ST* gout, const uint64_t* mask, const Geo
     using C = TB<T, NB, CPL, MARG>;
     const int nstrips = (geo.M + C::SW - 1) / C::SW;
     if (Ry <= 0) {
-        static int capacity = 0;  // per process: all devices of a node are the same part
+        // per process and instantiation: all devices of a node are the same part (a benign race:
+        // concurrent first calls compute the same value)
+        static std::atomic<int> capacity_cache{0};
+        int capacity = capacity_cache.load(std::memory_order_relaxed);
         if (capacity == 0) {
             int dev = 0, cus = 256, per_cu = 1;
             (void)hipGetDevice(&dev);
@@ -482,6 +486,7 @@ static void launch_tb_t(const ST* gin, ST* gout, const uint64_t* mask, const Geo
                     &per_cu, step_tb_kernel<XMODE, T, NB, CPL, MARG, ST>, C::NW * 64, 0) != hipSuccess || per_cu < 1)
                 per_cu = 1;
             capacity = cus * per_cu;
+            capacity_cache.store(capacity, std::memory_order_relaxed);
         }
         Ry = auto_chunk_rows(nrows, nstrips, T, capacity);
     }
