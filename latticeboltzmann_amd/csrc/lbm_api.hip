@@ -146,9 +146,12 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     if (rc == LBM_OK && (e = hipMalloc(&s->staging, s->staging_bytes)) != hipSuccess) bail(e, "hipMalloc(staging)");
     if (rc == LBM_OK && (e = hipEventCreate(&s->ev0)) != hipSuccess) bail(e, "hipEventCreate");
     if (rc == LBM_OK && (e = hipEventCreate(&s->ev1)) != hipSuccess) bail(e, "hipEventCreate");
-    if (rc == LBM_OK && (e = hipMemset(s->buf[0], 0, s->buf_bytes)) != hipSuccess) bail(e, "hipMemset");
-    if (rc == LBM_OK && (e = hipMemset(s->buf[1], 0, s->buf_bytes)) != hipSuccess) bail(e, "hipMemset");
-    if (rc == LBM_OK && (e = hipMemset(s->mask, 0, s->mask_bytes)) != hipSuccess) bail(e, "hipMemset");
+    // On the solver's own (non-blocking) stream: a hipMemset on the null stream returns before it
+    // has run and is NOT ordered against this stream, so it could wipe what the first upload wrote.
+    if (rc == LBM_OK && (e = hipMemsetAsync(s->buf[0], 0, s->buf_bytes, s->own_stream)) != hipSuccess) bail(e, "hipMemset");
+    if (rc == LBM_OK && (e = hipMemsetAsync(s->buf[1], 0, s->buf_bytes, s->own_stream)) != hipSuccess) bail(e, "hipMemset");
+    if (rc == LBM_OK && (e = hipMemsetAsync(s->mask, 0, s->mask_bytes, s->own_stream)) != hipSuccess) bail(e, "hipMemset");
+    if (rc == LBM_OK && (e = hipStreamSynchronize(s->own_stream)) != hipSuccess) bail(e, "hipStreamSynchronize");
     if (rc != LBM_OK) {
         lbm_destroy(s);
         return rc;

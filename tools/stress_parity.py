@@ -44,9 +44,9 @@ def main():
             s.fused_collide_stream(1)
             oc.run(ref, blocked, T, omega, surr, boundary)
             got = s.read_cells()
-            if not np.array_equal(got, ref):
+            if not np.array_equal(got, ref, equal_nan=True):  # a blown-up run (omega 1.7) is NaN on both sides
                 ok = False
-                w = np.argwhere(got != ref)
+                w = np.argwhere((got != ref) & ~(np.isnan(got) & np.isnan(ref)))
                 print(f"MISMATCH case {i}: N={N} M={M} T={T} cap={cap} rows={rows} {boundary} omega={omega} "
                       f"dens={dens}: {len(w)} values, first {w[:3].tolist()}", flush=True)
                 break
