@@ -157,3 +157,42 @@ def test_render_matches_the_reference_colour_map():
     assert (frame[blocked] == 0).all()
     assert diff.max() <= 1, f"max channel difference {diff.max()}"
     assert frame.std() > 10  # a real picture, not a constant
+
+
+def _launch_depths(T, cap, n_outer, tiny):
+    """The library's launch schedule after the initial collide-only launch (lbm_api.hip:
+    outer_iteration / advance): balanced launches no deeper than cap; tiny grids use depth 1."""
+    depths, first = [], True
+    for _ in range(n_outer):
+        rem = T - 1 if first else T
+        first = False
+        if rem <= 0:
+            continue
+        nl = -(-rem // cap)
+        for i in range(nl):
+            d = rem // nl + (1 if i < rem % nl else 0)
+            depths += [1] * d if tiny else [d]
+    return depths
+
+
+def test_fp16_random_schedules_are_bit_exact_against_the_emulation():
+    from latticeboltzmann_amd.lb_hip_kernel import Solver
+    rng = np.random.default_rng(5)
+    for case in range(40):
+        N, M = int(rng.integers(2, 90)), int(rng.integers(2, 300))
+        T, cap, n_outer = int(rng.integers(1, 8)), int(rng.integers(1, 7)), int(rng.integers(1, 4))
+        boundary = str(rng.choice(["reference", "periodic"]))
+        blocked = rng.random((N, M)) < float(rng.choice([0.0, 0.05, 0.3]))
+        cells = onp.perturbed_cells(N, M, seed=int(rng.integers(1 << 30)), amp=0.03)
+        surr = onp.ambient()
+        s = Solver(N, M, 0.25, inner_timesteps=T, boundary=boundary, dtype=np.float16)
+        s.set_tuning(cap, int(rng.choice([0, 5, 40])))
+        s.set_surroundings(surr)
+        s.upload_blocked(blocked)
+        s.upload_cells(cells)
+        s.fused_collide_stream(n_outer)
+        want = emulate_fp16_launches(cells, blocked, _launch_depths(T, cap, n_outer, M < 8 or N < 16),
+                                     0.25, surr, boundary)
+        got = s.read_cells()
+        s.close()
+        assert np.array_equal(got, want, equal_nan=True), (case, N, M, T, cap, n_outer, boundary)
