@@ -129,22 +129,25 @@ from oracle import lbm_ref as oc
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1,
                         device_id=torch.device("cuda:0"))
-G, M = 192, 320
 rng = np.random.default_rng(21)
-blocked = rng.random((G, M)) < 0.05
-cells = onp.perturbed_cells(G, M, seed=8, amp=0.05)
 surr = onp.ambient()
-slab = SlabSolver(G, M, 0.2, 0, 1, boundary="periodic", halo=4, device=0, dist=dist, self_seam=True)
-assert slab.seams and not slab.host_staged and slab.up == 0 and slab.down == 0
-slab.set_surroundings(surr)
-slab.upload_global(cells, blocked)
-ref = cells.copy()
-for n in (1, 3, 4, 9, 2, 16):
-    slab.step(n)
-    oc.run(ref, blocked, n, 0.2, surr, "periodic")
-    got = slab.read_cells()
-    assert np.array_equal(got, ref), (n, float(np.abs(got - ref).max()))
-slab.close()
+for G, M, halo, depth, steps in [(192, 320, 4, 1, (1, 3, 4, 9, 2, 16)), (64, 130, 1, 1, (1, 2, 5)),
+                                 (96, 200, 2, 6, (3, 4, 7)), (160, 300, 7, 6, (1, 7, 14, 5)),
+                                 (128, 64, 5, 3, (11, 2, 9))]:
+    blocked = rng.random((G, M)) < 0.05
+    cells = onp.perturbed_cells(G, M, seed=8 + halo, amp=0.05)
+    slab = SlabSolver(G, M, 0.2, 0, 1, boundary="periodic", halo=halo, device=0, dist=dist,
+                      self_seam=True, tb_max_depth=depth)
+    assert slab.seams and not slab.host_staged and slab.up == 0 and slab.down == 0
+    slab.set_surroundings(surr)
+    slab.upload_global(cells, blocked)
+    ref = cells.copy()
+    for n in steps:
+        slab.step(n)
+        oc.run(ref, blocked, n, 0.2, surr, "periodic")
+        got = slab.read_cells()
+        assert np.array_equal(got, ref), (G, M, halo, depth, n, float(np.abs(got - ref).max()))
+    slab.close()
 dist.destroy_process_group()
 print("rccl self-seam ok")
 """
