@@ -9,23 +9,25 @@
 // q_s(i) = y0 - (T-1) + i - 2(s-1), for ALL W columns of the window:
 //     stage 1     pulls level 0 straight from HBM (the same coalesced 768-byte pieces as the T=1
 //                 kernel), software-prefetched two iterations ahead in registers;
-//     stage 2..T  pull from a 4-row LDS ring of level s-1;
-//     stage s<T   writes its row into the LDS ring of level s, stage T stores to HBM.
-// One wave per (stage, 64-column block): T*NB waves, all running the same code.  Level 1 is
-// right in every window column; each further level loses one column at either window edge
-// (its neighbour lies outside the window), so only the inner W - 2*MARG columns (MARG = 8 >= T-1)
-// are stored: windows of neighbouring workgroups overlap by 16 columns (halo recompute, 6 %).
-// Output strips are 16 columns (64 bytes per population) aligned.  All stages run concurrently;
-// one barrier per iteration separates an iteration's ring writes from the next iteration's reads
-// (skew 2 per stage => ring depth 4).  Per T updates the cells are read once (1.07x with the
-// overlap, mostly L2 hits) and written once: HBM bytes per cell-update = 72/T (+ 3(T-1) warm-up
-// rows per chunk).  Every cell goes through the same pull/reflect/collide device functions as
-// the T=1 kernel, so results are bit-identical to T single updates.
+//     stage 2..T  pull from the LDS rings of level s-1 (struct TB below: 2 rows for the dy = -1
+//                 populations, 4 for the others and the blocked flags);
+//     stage s<T   writes its row into the LDS rings of level s, stage T stores to HBM.
+// One wave per (stage, 64*CPL columns): T*NB/CPL waves, all running the same code; with CPL = 2 a
+// lane owns two cells 64 columns apart and collide runs on packed fp32.  Level 1 is right in
+// every window column; each further level loses one column at either window edge (its neighbour
+// lies outside the window), so only the inner W - 2*MARG columns (MARG >= T-1, a multiple of 8)
+// are stored: windows of neighbouring workgroups overlap by 2*MARG columns (halo recompute,
+// 4-8 %).  All stages run concurrently; one barrier per iteration separates an iteration's ring
+// writes from the next iteration's reads (skew 2 per stage).  Per T updates the cells are read
+// once (1.04-1.07x with the overlap, mostly L2 hits) and written once: HBM bytes per cell-update =
+// 72/T (+ 3(T-1) warm-up rows per chunk).  Every cell goes through the same pull/reflect/collide
+// device functions as the T=1 kernel, so results are bit-identical to T single updates.
 //
 // All loads in the row loops are unconditional and straight-line (rows outside a stage's range are
-// clamped to a valid row instead of skipped), so that hipcc can use counted s_waitcnt vmcnt(N) and
-// the stage-1 prefetch really stays in flight across two iterations and barriers.  Only stage 1
-// touches the bit-packed mask; it hands each cell's blocked flag to the later stages through LDS.
+// clamped to a valid row instead of skipped), and nothing else in the stage-1 loop touches vector
+// memory, so that hipcc can use counted s_waitcnt vmcnt(N) and the prefetch really stays in
+// flight across two iterations and barriers.  Only stage 1 touches the bit-packed mask; it hands
+// each cell's blocked flag to the later stages through LDS.
 #include <atomic>
 #include <type_traits>
 
