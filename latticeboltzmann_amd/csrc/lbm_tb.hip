@@ -381,6 +381,11 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         }
     };
 
+    // does this stage produce row r?  Also true for the phantom row below the last domain row
+    // (to_lds); wave-uniform
+    auto live = [&](int r) {
+        return (r >= rlo && r < rhi) || (XMODE != XMODE_PERIODIC && s < T && r == qhi);
+    };
     auto run = [&](auto xedge) {
         int q = qstart;
         if (s == 1) {
@@ -395,13 +400,17 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
                 bool blocked[CPL];
 #pragma unroll
                 for (int k = 0; k < Q; k++) a[k] = pr[k];
-                inlet_fix(xedge, clampr(q), a);
 #pragma unroll
                 for (int c = 0; c < CPL; c++) blocked[c] = (mw[c] >> mbit[c]) & 1ull;
                 load_row(xedge, q + PF, pr, mw);
-                reflect_v(a, blocked);
-                collide_v(a, blocked, omega);
-                to_lds(xedge, ph, q, a, blocked);
+                // rows outside this stage's range (pipeline fill and drain: 3(T-1) of the
+                // iterations) are nobody's input: skip their arithmetic, keep loads and barrier
+                if (live(q)) {
+                    inlet_fix(xedge, clampr(q), a);
+                    reflect_v(a, blocked);
+                    collide_v(a, blocked, omega);
+                    to_lds(xedge, ph, q, a, blocked);
+                }
                 q += 1;
                 __syncthreads();
             };
@@ -414,16 +423,15 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         } else {
             ST* orow = gout + (long long)(wrap_row(clampr(q)) + G) * RS;
             auto it = [&](auto ph) {
-                V a[Q];
-                bool blocked[CPL];
-                gather(xedge, ph, q, a, blocked);
-                reflect_v(a, blocked);
-                collide_v(a, blocked, omega);
-                if (s < T) {
-                    to_lds(xedge, ph, q, a, blocked);
-                } else {
-                    const bool in = q >= rlo && q < rhi;
-                    if (in) {
+                if (live(q)) {
+                    V a[Q];
+                    bool blocked[CPL];
+                    gather(xedge, ph, q, a, blocked);
+                    reflect_v(a, blocked);
+                    collide_v(a, blocked, omega);
+                    if (s < T) {
+                        to_lds(xedge, ph, q, a, blocked);
+                    } else {
 #pragma unroll
                         for (int c = 0; c < CPL; c++) {
                             if (stored[c]) {
