@@ -125,7 +125,7 @@ int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame);
 /* Tuning of the INNER_TIMESTEPS > 1 path (replaces the reference's per-GPU presets,
  * latticeboltzmann.py:55-71): deepest temporal-blocking launch (1..6; inner_timesteps is split
  * into balanced launches no deeper than this; 1 = plain kernel only; 0 = automatic, the default:
- * 6, but 1 for grids below 2^19 cells, where the plain kernel is faster) and rows per workgroup
+ * 6, but 1 for grids below 2^17 cells, which are launch-latency-bound either way) and rows per workgroup
  * chunk (0 = chosen by the library per launch). */
 int lbm_set_tuning(lbm_solver* s, int tb_max_depth, int tb_rows);
 /* One update restricted to rows [row0, row0+nrows) (may extend into ghost rows), written into the

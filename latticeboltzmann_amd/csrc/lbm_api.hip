@@ -275,9 +275,9 @@ int lbm_halo_valid(lbm_solver* s, int* rows) {
     return LBM_OK;
 }
 
-// Deepest launch in use.  Automatic: TB_DEFAULT_T, but the plain kernel for grids so small that the
-// row pipeline of the LDS kernel cannot fill the chip (measured crossover ~0.5 M cells:
-// 400 x 800 runs 56 GLUPS at depth 1 against 40 at depth 6, 1024 x 1024 61 against 106).
+// Deepest launch in use.  Automatic: TB_DEFAULT_T, but the plain kernel for grids below 2^17 cells,
+// where both are bound by launch latency alike (128 x 256: 8.3 GLUPS either way; from 400 x 800 on
+// the LDS kernel wins: 62 against 56 GLUPS).
 static int depth_cap(const lbm_solver* s) {
     if (s->tb_max > 0) return std::min(s->tb_max, TB_MAX_T);
     return (long long)s->geo.N * s->geo.M < TB_MIN_CELLS ? 1 : TB_DEFAULT_T;

@@ -8,7 +8,7 @@ hipError_t launch_step(const void* gin, void* gout, const uint64_t* mask, const 
                        bool half, int row0, int nrows, hipStream_t st);
 constexpr int TB_MAX_T = 6;      // deepest launch the LDS kernel is instantiated for
 constexpr int TB_DEFAULT_T = 6;  // deepest launch used unless lbm_set_tuning says otherwise
-constexpr long long TB_MIN_CELLS = 1 << 19;  // smaller grids: plain kernel (automatic tuning only)
+constexpr long long TB_MIN_CELLS = 1 << 17;  // smaller grids: plain kernel (automatic tuning only)
 hipError_t launch_step_tb(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
                           bool half, int T, int row0, int nrows, int Ry, hipStream_t st);
 hipError_t launch_collide(void* f, const uint64_t* mask, const Geom& geo, bool half, int row0,

@@ -461,14 +461,14 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
 }
 
 // Rows per workgroup chunk.  A workgroup runs Ry + 3(T-1) iterations, and the grid is executed
-// in rounds of (CUs x resident workgroups per CU): pick the Ry in [16, 512] that minimises
+// in rounds of (CUs x resident workgroups per CU): pick the Ry in [4, 512] that minimises
 // rounds x iterations (tail effect and pipeline warm-up against each other; small grids get
 // short chunks so that every CU has a workgroup).
 static int auto_chunk_rows(int nrows, int nstrips, int T, int capacity) {
     long long best_cost = -1;
-    int best = nrows < 16 ? (nrows > 0 ? nrows : 1) : 16;
-    for (int ry = 512; ry >= 16; ry -= 8) {
-        if (ry > nrows && ry != 16) continue;
+    int best = nrows < 4 ? (nrows > 0 ? nrows : 1) : 4;
+    for (int ry = 512; ry >= 4; ry -= 4) {
+        if (ry > nrows && ry != 4) continue;
         const int r = ry < nrows ? ry : nrows;
         const long long wgs = (long long)nstrips * ((nrows + r - 1) / r);
         const long long rounds = (wgs + capacity - 1) / capacity;

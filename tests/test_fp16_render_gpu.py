@@ -100,7 +100,7 @@ def test_fp16_cavity_within_1e2_of_fp32(T):
     surr = onp.ambient()
     cells = onp.initial_cells(blocked, surr)
     s = Solver(N, M, 0.3, inner_timesteps=T, boundary="reference", dtype=np.float16)
-    s.set_tuning(6, 0)  # keep the LDS kernel on this small grid (automatic tuning would not)
+    s.set_tuning(6, 0)  # pin the LDS kernel (automatic tuning uses the plain kernel on tiny grids)
     s.set_surroundings(surr)
     s.upload_blocked(blocked)
     s.upload_cells(cells)

@@ -116,7 +116,7 @@ def test_zero_density_and_non_finite_cells():
     for T in (1, 3):
         from latticeboltzmann_amd.lb_hip_kernel import Solver
         s = Solver(N, M, 0.5, inner_timesteps=T, boundary="reference")
-        s.set_tuning(6, 0)  # keep the LDS kernel on this small grid
+        s.set_tuning(6, 0)  # pin the LDS kernel (automatic tuning uses the plain kernel on tiny grids)
         s.set_surroundings(surr)
         s.upload_blocked(blocked)
         s.upload_cells(cells)
@@ -152,7 +152,7 @@ def test_extreme_magnitudes_take_the_exact_division_path(T):
     cells[40, 610] = [1e-20, 0, 0, 0, 1, 0, 0, 0, -1e-20]
     surr = onp.ambient()
     s = Solver(N, M, 0.4, inner_timesteps=T, boundary="periodic")
-    s.set_tuning(6, 0)  # keep the LDS kernel on this small grid
+    s.set_tuning(6, 0)  # pin the LDS kernel (automatic tuning uses the plain kernel on tiny grids)
     s.set_surroundings(surr)
     s.upload_blocked(blocked)
     s.upload_cells(cells)

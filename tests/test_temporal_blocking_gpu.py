@@ -59,7 +59,7 @@ def test_tb_cylinder():
     cells = onp.initial_cells(blocked, surr)
     from latticeboltzmann_amd.lb_hip_kernel import Solver
     s = Solver(400, 800, 0.01, inner_timesteps=4, boundary="reference")
-    s.set_tuning(4, 0)  # automatic tuning would pick the plain kernel for a grid this small
+    s.set_tuning(4, 0)  # pin the depth (automatic tuning depends on the grid size)
     s.set_surroundings(surr)
     s.upload_blocked(blocked)
     s.upload_cells(cells)
