@@ -132,7 +132,7 @@ int lbm_set_tuning(lbm_solver* s, int tb_max_depth, int tb_rows);
  * other cell buffer.  finish != 0 ends the update (buffer swap, step count, one ghost row
  * consumed); finish == 0 leaves it open so that further row ranges of the same update can follow:
  * the building block of the overlapped slab schedule (edge rows first, interior while the halos
- * travel). */
+ * travel).  While an update is open, the other stepping calls are rejected. */
 int lbm_step_rows(lbm_solver* s, int row0, int nrows, int finish);
 /* Same as lbm_fused_collide_stream, bracketed by HIP events on the solver's stream; blocks and
  * returns the elapsed device time.  For bench.py's roofline figure. */

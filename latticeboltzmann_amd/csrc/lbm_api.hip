@@ -47,6 +47,7 @@ struct lbm_solver {
     bool pulled;       // buf[cur] holds g = collide(f_{steps-1}); false: holds f_steps itself
     int64_t steps;
     int ghost_valid;   // valid ghost rows beyond each seam
+    bool open_update;  // lbm_step_rows(finish = 0) has written part of the next state
     void* staging;     // device staging for host-layout windows
     size_t staging_bytes;
     uint8_t* frame_dev;
@@ -220,6 +221,7 @@ int lbm_upload_cells(lbm_solver* s, const float* cells, int row0, int nrows) {
     if (!cells) return fail(LBM_ERR_INVALID, "cells is null");
     int rc = check_rows(s, row0, nrows, true);
     if (rc) return rc;
+    s->open_update = false;
     if (s->pulled) {  // a new initial condition: back to the freshly-uploaded state
         // the buffer holds post-collision populations now; a partial upload would mix the two
         if (row0 > 0 || row0 + nrows < s->geo.N)
@@ -246,6 +248,7 @@ int lbm_init_equilibrium(lbm_solver* s, float rho, float u_row, float u_col, flo
                          int64_t row_offset, int64_t global_rows) {
     ENTER(s);
     s->pulled = false;
+    s->open_update = false;
     s->steps = 0;
     s->ghost_valid = s->geo.G;
     HIPCHK(launch_init_equilibrium(s->buf[s->cur], s->geo, s->half, rho, u_row, u_col, amp, seed,
@@ -290,6 +293,9 @@ static int depth_cap(const lbm_solver* s) {
 // seam each update consumes one ghost row.
 static int advance(lbm_solver* s, long long total, int max_depth) {
     const Geom& g = s->geo;
+    if (total > 0 && s->open_update)
+        return fail(LBM_ERR_INVALID, "an update opened by lbm_step_rows(finish = 0) is unfinished: "
+                                     "finish it (finish != 0) before stepping further");
     const bool seam = seam_top(s) || seam_bot(s);
     while (total > 0) {
         if (!s->pulled) {
@@ -376,6 +382,7 @@ int lbm_step_rows(lbm_solver* s, int row0, int nrows, int finish) {
                                      "lbm_fused_collide_stream once after an upload)");
     HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, s->geo, s->xmode, s->half, row0,
                        nrows, s->stream));
+    s->open_update = !finish;
     if (finish) {
         s->cur ^= 1;
         s->steps++;

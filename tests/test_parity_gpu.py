@@ -191,6 +191,18 @@ def test_error_behaviour_of_the_abi():
     assert L.lbm_read_moments(s._h, None, None, 0, 1, 0, 1) != 0
     assert L.lbm_fused_collide_stream(s._h, -1) != 0
     assert L.lbm_fused_collide_stream(None, 1) != 0 and b"null solver" in L.lbm_last_error()
+    # an update left open by step_rows(finish=0) blocks further stepping until it is finished
+    s.step_rows(0, 10, False)
+    with pytest.raises(RuntimeError, match="unfinished"):
+        s.fused_collide_stream(1)
+    with pytest.raises(RuntimeError, match="unfinished"):
+        s.advance(2)
+    s.step_rows(10, 14, True)
+    assert s.steps_done == 3
+    cells3 = oc.run(cells.copy(), np.zeros((24, 100), bool), 3, 0.3, onp.ambient())
+    assert np.array_equal(s.read_cells(), cells3)
+    s.upload_cells(cells)
+    s.fused_collide_stream(2)
     # the solver is still usable and correct after the rejected calls
     ref = oc.run(cells.copy(), np.zeros((24, 100), bool), 2, 0.3, onp.ambient())
     assert np.array_equal(s.read_cells(), ref)
