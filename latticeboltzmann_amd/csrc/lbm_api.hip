@@ -288,7 +288,7 @@ static int depth_cap(const lbm_solver* s) {
 
 // Advance the numpy-visible state by `total` updates.  Right after an upload the buffer holds f:
 // the first update only collides in place (its stream + reflect half is deferred into the next
-// kernel or into the observers).  Afterwards updates go in launches of depth t <= max_depth:
+// kernel or into the observers).  Afterwards updates go in balanced launches of depth t <= max_depth:
 // t = 1 is the plain fused kernel, t > 1 the LDS temporal-blocking kernel (lbm_tb.hip).  At a
 // seam each update consumes one ghost row.
 static int advance(lbm_solver* s, long long total, int max_depth) {
@@ -308,7 +308,10 @@ static int advance(lbm_solver* s, long long total, int max_depth) {
         if (seam && s->ghost_valid < 1)
             return fail(LBM_ERR_INVALID, "ghost rows exhausted: exchange halos (lbm_halo_region) and "
                                          "call lbm_halo_mark_filled before stepping further");
-        int t = (int)std::min<long long>(total, max_depth);
+        // balanced launches: 7 updates at depth cap 6 go as 4 + 3, not 6 + 1 (a depth-1 launch
+        // costs more than half a depth-6 one)
+        const long long nl = (total + max_depth - 1) / max_depth;
+        int t = (int)((total + nl - 1) / nl);
         if (seam) t = std::min(t, s->ghost_valid);
         if (g.M < 8 || g.N < 16) t = 1;  // tiny domains: rows wrap at most once in the strip pipeline
         const int ext = seam ? s->ghost_valid - t : 0;
