@@ -13,7 +13,7 @@ using namespace lbm;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { F_NT_ST = 1, F_NT_LD = 2, F_NO_REMAP = 4, F_ROWS4 = 8, F_PERSIST = 16, F_TWO = 32, F_PK = 64, F_PKROW = 128, F_ROWXCD = 256, F_ROWXCD2 = 512 };
+enum { F_NT_ST = 1, F_NT_LD = 2, F_NO_REMAP = 4, F_ROWS4 = 8, F_PERSIST = 16, F_TWO = 32, F_PK = 64, F_PKROW = 128, F_ROWXCD = 256, F_ROWXCD2 = 512, F_GROUPED = 1024 };
 
 template <int FLAGS>
 __device__ __forceinline__ float ldx(const float* p) {
@@ -33,9 +33,12 @@ __device__ __forceinline__ void pullp(const float* __restrict__ g, const Geom& g
     int x = xb * LANES + lane;
     int xm = x + 1; xm = xm >= M ? 0 : xm;
     int xp = x - 1; xp = xp < 0 ? M - 1 : xp;
-    const int off0 = xb * CHUNK + lane;
-    const int offm = (xm >> 6) * CHUNK + (xm & 63);
-    const int offp = (xp >> 6) * CHUNK + (xp & 63);
+    // F_GROUPED: row = [dy group (3)][xb][3 slots][64 lanes] instead of [xb][9 slots][64 lanes]: the
+    // three populations a destination row pulls from one source row are contiguous across blocks
+    const int BS = (FLAGS & F_GROUPED) ? 3 * LANES : CHUNK;
+    const int off0 = xb * BS + lane;
+    const int offm = (xm >> 6) * BS + (xm & 63);
+    const int offp = (xp >> 6) * BS + (xp & 63);
     int yu = y == 0 ? geo.N - 1 : y - 1;
     int yd = y == geo.N - 1 ? 0 : y + 1;
     const float* r0 = g + (long long)y * geo.rowStride;
@@ -43,7 +46,9 @@ __device__ __forceinline__ void pullp(const float* __restrict__ g, const Geom& g
     const float* rd = g + (long long)yd * geo.rowStride;
 #pragma unroll
     for (int k = 0; k < Q; k++) {
-        const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
+        const int dy = dy_of(k), dx = dx_of(k);
+        const int sl = (FLAGS & F_GROUPED) ? (slot_of(k) / 3) * (geo.Mb * 3 * LANES) + (slot_of(k) % 3) * LANES
+                                           : slot_of(k) * LANES;
         const float* rb = dy == 1 ? ru : (dy == 0 ? r0 : rd);
         const int off = dx == 1 ? offp : (dx == 0 ? off0 : offm);
         t[k] = ldx<FLAGS>(rb + off + sl);
@@ -59,6 +64,13 @@ __device__ __forceinline__ void do_tile(const float* __restrict__ gin, float* __
     const bool blocked = (mrow >> lane) & 1ull;
     reflect(a, blocked);
     collide(a, blocked, geo.omega);
+    if (FLAGS & F_GROUPED) {
+        float* o = gout + (long long)y * geo.rowStride + (long long)xb * (3 * LANES) + lane;
+#pragma unroll
+        for (int k = 0; k < Q; k++)
+            stx<FLAGS>(o + (slot_of(k) / 3) * (geo.Mb * 3 * LANES) + (slot_of(k) % 3) * LANES, a[k]);
+        return;
+    }
     float* o = gout + (long long)y * geo.rowStride + (long long)xb * CHUNK + lane;
 #pragma unroll
     for (int k = 0; k < Q; k++) stx<FLAGS>(o + slot_of(k) * LANES, a[k]);
@@ -224,7 +236,7 @@ int main(int argc, char** argv) {
         mk<0>("base"), mk<F_NT_ST>("nt_store"), mk<F_NT_ST | F_NT_LD>("nt_both"), mk<F_NT_LD>("nt_load"),
         mk<F_NO_REMAP>("no_remap"), mk<F_ROWS4>("rows4"), mk<F_ROWS4 | F_NT_ST>("rows4_ntst"),
         mk<F_TWO | F_NT_ST>("two_rows_ntst"), mk<F_PK | F_NT_ST>("pk_cols_ntst"), mk<F_PKROW | F_NT_ST>("pk_rows_ntst"),
-        mk<F_PK>("pk_cols"), mk<F_ROWXCD | F_NT_ST>("rowxcd_ntst"), mk<F_ROWXCD2 | F_NT_ST>("rowxcd2_ntst"),
+        mk<F_PK>("pk_cols"), mk<F_GROUPED | F_NT_ST>("grouped_ntst"), mk<F_GROUPED>("grouped"), mk<F_ROWXCD | F_NT_ST>("rowxcd_ntst"), mk<F_ROWXCD2 | F_NT_ST>("rowxcd2_ntst"),
     };
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     std::vector<std::vector<float>> ms(vars.size());
