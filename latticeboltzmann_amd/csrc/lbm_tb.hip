@@ -71,6 +71,9 @@
 #ifndef LBM_TB_MARG6
 #define LBM_TB_MARG6 8
 #endif
+#ifndef LBM_TB_NODEAD
+#define LBM_TB_NODEAD 0
+#endif
 #ifndef LBM_TB_PF
 #define LBM_TB_PF 2
 #endif
@@ -456,6 +459,13 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
             }
         }
     };
+    // A wave whose columns all lie beyond what the strip needs (the last strip of a row is
+    // usually narrower than the window) only keeps the barriers company: no loads, no arithmetic.
+    const int need_hi = min(xo + C::SW, M) + MARG;  // logical columns at or beyond: nobody's input
+    if (!LBM_TB_NODEAD && xo - MARG + j * (64 * CPL) >= need_hi) {
+        for (int i = 0; i < nit; i++) __syncthreads();
+        return;
+    }
     if (wave_xedge) run(std::true_type{});
     else run(std::false_type{});
 }
