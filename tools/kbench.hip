@@ -284,6 +284,34 @@ int main(int argc, char** argv) {
             printf("%-24s median %.3f ms  %.3f TB/s\n", nm[mode], t[t.size() / 2], vol * n * 4 / t[t.size() / 2] / 1e9);
         }
     }
+    if (argc > 5) {
+        // relative placement of the two ping-pong buffers: does an offset between them change the
+        // bandwidth of the fused kernel (HBM channel / bank aliasing of the read and write streams)?
+        float* big; const size_t slack = 64ull << 20;
+        CHECK(hipMalloc(&big, 2 * bytes + 2 * slack));
+        printf("buffers: a=%p b=%p (separate hipMallocs), big=%p\n", (void*)a, (void*)b, (void*)big);
+        const size_t offs[] = {0, 256, 1024, 4096, 16384, 65536, 262144, 1048576, 2097152 + 4096, 8388608 + 768,
+                               33554432 + 2304, 589824, 589824 * 2, 589824 * 3 + 768};
+        for (size_t oi = 0; oi < sizeof offs / sizeof offs[0]; oi++) {
+            float* pa = big;
+            float* pb = (float*)((char*)big + bytes + offs[oi]);
+            hipLaunchKernelGGL(initk, dim3((unsigned)(((long long)N * geo.rowStride + 255) / 256)), dim3(256), 0, 0, pa, geo);
+            std::vector<float> t;
+            for (int r = 0; r < rounds + 1; r++) {
+                CHECK(hipEventRecord(e0, 0));
+                for (int i = 0; i < reps; i++) {
+                    hipLaunchKernelGGL(kvar<F_NT_ST>, dim3((unsigned)(ntiles / 4)), dim3(256), 0, 0, (const float*)pa, pb, (const uint64_t*)mask, geo);
+                    std::swap(pa, pb);
+                }
+                CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+                float ms1; CHECK(hipEventElapsedTime(&ms1, e0, e1));
+                if (r > 0) t.push_back(ms1 / reps);
+            }
+            std::sort(t.begin(), t.end());
+            printf("offset %10zu B: %.3f ms  %.3f TB/s\n", offs[oi], t[t.size() / 2], (double)N * M * 72 / t[t.size() / 2] / 1e9);
+        }
+        CHECK(hipFree(big));
+    }
     float chk[4]; CHECK(hipMemcpy(chk, a + 12345 * 64, sizeof chk, hipMemcpyDeviceToHost));
     printf("check %g %g %g %g\n", chk[0], chk[1], chk[2], chk[3]);
     const double cells = (double)N * M;
