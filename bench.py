@@ -232,7 +232,9 @@ def main():
                                    f"INNER_TIMESTEPS=1 (BASELINE.json configs[1])",
                        "rows_per_gpu": rows, "cols": cols, "inner_timesteps": 1,
                        "decomposition": "single domain" if world == 1 else
-                                        f"{world} y-slabs, halo {args.halo}, RCCL send/recv every {args.halo} steps"
+                                        f"{world} y-slabs, halo {args.halo}, "
+                                        f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (rehearsal)'} "
+                                        f"send/recv every {args.halo} steps"
                                         + (f", LDS launches up to {args.depth} deep" if args.depth > 1 else "")},
             "frac_of_hbm_roofline": glups * BYTES_PER_UPDATE / (HBM_PEAK_GBS * world),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
