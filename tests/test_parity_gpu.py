@@ -218,3 +218,34 @@ def test_error_behaviour_of_the_abi():
     s2.fused_collide_stream(2)
     assert np.isfinite(s2.read_cells()).all()
     s2.close()
+
+
+@pytest.mark.parametrize("T", [1, 6])
+@pytest.mark.parametrize("tag,boundary", [("cyl64x128_reference", "reference"),
+                                          ("cyl64x128_vortex", "reference"),
+                                          ("rand48x80_periodic", "periodic")])
+def test_committed_golden_fields(tag, boundary, T):
+    """The HIP path against the committed fixtures alone (tests/golden/fields_*.npz: rho, u and a
+    sha256 of the cells after 1 / 10 / 100 / 1000 steps), plain kernel and LDS kernel."""
+    import hashlib
+    import os
+    from latticeboltzmann_amd.lb_hip_kernel import Solver
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"fields_{tag}.npz"))
+    N, M = (int(v) for v in z["shape"])
+    blocked = np.unpackbits(z["blocked_bits"])[:N * M].reshape(N, M).astype(bool)
+    surr, omega = z["surroundings"], float(z["omega"])
+    cells = onp.initial_cells(blocked, surr) if tag.startswith("cyl") else onp.perturbed_cells(N, M, seed=0, amp=0.01)
+    s = Solver(N, M, omega, boundary=boundary)
+    s.set_tuning(T, 0)
+    s.set_surroundings(surr)
+    s.upload_blocked(blocked)
+    s.upload_cells(cells)
+    done = 0
+    for c in sorted(int(k.split("_")[1]) for k in z.files if k.startswith("rho_")):
+        s.advance(c - done)
+        done = c
+        u, p = s.read_moments()
+        assert np.array_equal(p, z[f"rho_{c}"]) and np.array_equal(u, z[f"u_{c}"]), (tag, c)
+        sha = np.frombuffer(hashlib.sha256(s.read_cells().tobytes()).digest(), np.uint8)
+        assert np.array_equal(sha, z[f"cells_sha_{c}"]), (tag, c)
+    s.close()
