@@ -134,6 +134,12 @@ int lbm_set_tuning(lbm_solver* s, int tb_max_depth, int tb_rows);
  * the building block of the overlapped slab schedule (edge rows first, interior while the halos
  * travel).  While an update is open, the other stepping calls are rejected. */
 int lbm_step_rows(lbm_solver* s, int row0, int nrows, int finish);
+/* The same with `depth` (1..6) updates in one launch: rows [row0, row0+nrows) jump `depth` time
+ * levels into the other buffer (LDS kernel for depth > 1); their inputs, rows
+ * [row0-depth, row0+nrows+depth), must be owned rows, valid ghost rows or beyond a domain edge.
+ * All row ranges of one open update use the same depth; finish != 0 consumes `depth` ghost rows.
+ * With it the last `depth` updates of a halo cycle overlap with the exchange as well. */
+int lbm_advance_rows(lbm_solver* s, int row0, int nrows, int depth, int finish);
 /* Same as lbm_fused_collide_stream, bracketed by HIP events on the solver's stream; blocks and
  * returns the elapsed device time.  For bench.py's roofline figure. */
 int lbm_fused_collide_stream_timed(lbm_solver* s, int n_outer, float* elapsed_ms);

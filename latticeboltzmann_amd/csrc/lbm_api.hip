@@ -47,7 +47,8 @@ struct lbm_solver {
     bool pulled;       // buf[cur] holds g = collide(f_{steps-1}); false: holds f_steps itself
     int64_t steps;
     int ghost_valid;   // valid ghost rows beyond each seam
-    bool open_update;  // lbm_step_rows(finish = 0) has written part of the next state
+    bool open_update;  // lbm_advance_rows(finish = 0) has written part of the next state ...
+    int open_depth;    // ... which lies this many updates ahead
     void* staging;     // device staging for host-layout windows
     size_t staging_bytes;
     uint8_t* frame_dev;
@@ -376,22 +377,42 @@ int lbm_set_tuning(lbm_solver* s, int tb_max_depth, int tb_rows) {
     return LBM_OK;
 }
 
-int lbm_step_rows(lbm_solver* s, int row0, int nrows, int finish) {
+int lbm_advance_rows(lbm_solver* s, int row0, int nrows, int depth, int finish) {
     ENTER(s);
     int rc = check_rows(s, row0, nrows, true);
     if (rc) return rc;
     if (!s->pulled)
-        return fail(LBM_ERR_INVALID, "lbm_step_rows needs a stepped state (call "
+        return fail(LBM_ERR_INVALID, "lbm_step_rows / lbm_advance_rows need a stepped state (call "
                                      "lbm_fused_collide_stream once after an upload)");
-    HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, s->geo, s->xmode, s->half, row0,
-                       nrows, s->stream));
+    const Geom& g = s->geo;
+    if (depth < 1 || depth > TB_MAX_T) return fail(LBM_ERR_INVALID, "depth must be in [1, %d]", TB_MAX_T);
+    if (depth > 1 && (g.M < 8 || g.N < 16))
+        return fail(LBM_ERR_UNSUPPORTED, "grids below 16 x 8 only take depth 1");
+    if (s->open_update && depth != s->open_depth)
+        return fail(LBM_ERR_INVALID, "the open update has depth %d, not %d", s->open_depth, depth);
+    // inputs at a seam must be valid ghost rows
+    if (nrows > 0 && ((seam_top(s) && row0 - depth < -s->ghost_valid) ||
+                      (seam_bot(s) && row0 + nrows + depth > g.N + s->ghost_valid)))
+        return fail(LBM_ERR_INVALID, "rows [%d, %d) at depth %d need more than the %d valid ghost rows",
+                    row0, row0 + nrows, depth, s->ghost_valid);
+    if (depth == 1)
+        HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, row0, nrows,
+                           s->stream));
+    else
+        HIPCHK(launch_step_tb(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, depth, row0,
+                              nrows, s->tb_rows, s->stream));
     s->open_update = !finish;
+    s->open_depth = depth;
     if (finish) {
         s->cur ^= 1;
-        s->steps++;
-        if ((seam_top(s) || seam_bot(s)) && s->ghost_valid > 0) s->ghost_valid--;
+        s->steps += depth;
+        if (seam_top(s) || seam_bot(s)) s->ghost_valid = std::max(0, s->ghost_valid - depth);
     }
     return LBM_OK;
+}
+
+int lbm_step_rows(lbm_solver* s, int row0, int nrows, int finish) {
+    return lbm_advance_rows(s, row0, nrows, 1, finish);
 }
 
 int lbm_fused_collide_stream_timed(lbm_solver* s, int n_outer, float* elapsed_ms) {

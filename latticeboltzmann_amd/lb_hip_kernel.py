@@ -30,7 +30,7 @@ SYMBOLS = [
     "lbm_sync", "lbm_steps_done", "lbm_read_cells", "lbm_read_moments", "lbm_read_blocked",
     "lbm_render", "lbm_halo_region", "lbm_mask_halo_region", "lbm_halo_valid",
     "lbm_halo_mark_filled", "lbm_set_tuning", "lbm_advance", "lbm_host_alloc",
-    "lbm_host_free",
+    "lbm_host_free", "lbm_advance_rows",
 ]
 
 
@@ -124,6 +124,7 @@ def load_library(path=LIB_PATH):
         "lbm_advance": ([H, c_int], c_int),
         "lbm_host_alloc": ([ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)], c_int),
         "lbm_host_free": ([ctypes.c_void_p], c_int),
+        "lbm_advance_rows": ([H, c_int, c_int, c_int, c_int], c_int),
     }
     assert set(protos) == set(SYMBOLS)
     for name, (argtypes, restype) in protos.items():
@@ -252,6 +253,10 @@ class Solver:
     def step_rows(self, row0, nrows, finish):
         """One update of rows [row0, row0+nrows) into the other buffer; finish=True closes it."""
         _check(self._L.lbm_step_rows(self._h, row0, nrows, int(bool(finish))))
+
+    def advance_rows(self, row0, nrows, depth, finish):
+        """`depth` updates of rows [row0, row0+nrows) in one launch into the other buffer."""
+        _check(self._L.lbm_advance_rows(self._h, row0, nrows, depth, int(bool(finish))))
 
     def fused_collide_stream_timed(self, n_outer):
         """Returns the device time in ms (HIP events on the solver's stream)."""

@@ -6,11 +6,13 @@ ghost rows on each seam.  The halo is deep: after one exchange the ghost rows ar
 updates (each update recomputes one ghost row less), so neighbours talk once every `halo` steps.
 
 Schedule of one cycle (halo = H), on the compute stream C and the communication stream K:
-    C: H-1 full updates (row range shrinking by one ghost row per update)
-    C: last update, edge rows only: [0, H) and [N-H, N)          -> event E1
+    C: H-d full updates (row range shrinking by one ghost row per update)
+    C: last d updates in one jump, edge rows only: [0, H) and [N-H, N)   -> event E1
     K: wait E1; grouped send/recv of those rows into the neighbours' ghost rows -> event E2
-    C: last update, interior rows [H, N-H)  (runs while the halos travel)
+    C: the same jump for the interior rows [H, N-H)  (runs while the halos travel)
     C: wait E2
+d = 1 with the plain kernel; with the LDS kernel (tb_max_depth > 1) d = min(tb_max_depth, H), so a
+cycle of H <= 6 updates is three launches: two edge bands, then the interior.
 The exchange is a grouped torch.distributed send/recv (RCCL over xGMI on the GPU box, gloo in the
 CPU tests): `exchange_halos` below is backend-agnostic and is what tests/test_slabs_gloo.py drives.
 There is no reduction or other collective on the data path.
@@ -61,23 +63,32 @@ def exchange_halos(dist, send_top, send_bot, recv_top, recv_bot, up, down, group
 
 def advance(b, n):
     """The slab schedule (module docstring) over a backend `b` that provides is_fresh(),
-    halo_valid(), full_updates(k), edge_update(), exchange(), interior_update().  SlabSolver is the
-    GPU backend; tests/test_slabs_gloo.py drives the same function with a numpy backend."""
+    halo_valid(), last_depth(), full_updates(k), edge_update(d), exchange(), interior_update(d).
+    SlabSolver is the GPU backend; tests/test_slabs_gloo.py drives the same function with a numpy
+    backend.  last_depth() = how many updates the split jump at the end of a cycle covers (1 for
+    the plain kernel; up to 6 with the LDS kernel, so that the whole cycle can run deep)."""
     while n > 0:
         if b.is_fresh():  # first update after an upload only collides: consumes no ghost row
             b.full_updates(1)
             n -= 1
             continue
         hv = b.halo_valid()
-        if hv > 1:
-            k = min(n, hv - 1)
+        # the hv updates left in the cycle go in ceil(hv / D) launches of balanced depth; the last
+        # of them is the split jump (7 = 4 + 3 at D = 6, not 1 + 6: a depth-1 launch costs more
+        # than half a deep one)
+        dl = hv // -(-hv // b.last_depth())
+        if hv > dl:  # everything before the split jump: full launches
+            k = min(n, hv - dl)
             b.full_updates(k)
             n -= k
             continue
-        b.edge_update()      # last update of the cycle: rows the neighbours need, first
-        b.exchange()         # ... travel on the communication stream ...
-        b.interior_update()  # ... while the interior rows are updated
-        n -= 1
+        if n < hv:  # the cycle does not end within this call
+            b.full_updates(n)
+            return
+        b.edge_update(hv)      # last hv updates of the cycle: rows the neighbours need, first
+        b.exchange()           # ... travel on the communication stream ...
+        b.interior_update(hv)  # ... while the interior rows jump the same hv updates
+        n -= hv
 
 
 class _DevMem:
@@ -113,6 +124,9 @@ class SlabSolver:
             top_edge=hk.YEDGE_SEAM if self.up is not None else hk.YEDGE_DOMAIN,
             bottom_edge=hk.YEDGE_SEAM if self.down is not None else hk.YEDGE_DOMAIN)
         self.solver.set_tuning(tb_max_depth, 0)
+        self.tb_max_depth = tb_max_depth
+        if M < 8 or self.N < 16:  # the LDS kernel does not take grids this small
+            self.tb_max_depth = 1
         self.compute = torch.cuda.Stream(device=self.device)
         self.comm = torch.cuda.Stream(device=self.device)
         self.solver.set_stream(self.compute.cuda_stream)
@@ -176,15 +190,18 @@ class SlabSolver:
     def halo_valid(self):
         return self.solver.halo_valid
 
+    def last_depth(self):
+        return max(1, min(self.tb_max_depth, self.halo))
+
     def full_updates(self, k):
         self._wait_pending()
         self.solver.advance(k)  # LDS temporal blocking when tb_max_depth > 1 (set_tuning)
         self._fresh = False
 
-    def edge_update(self):
+    def edge_update(self, depth=1):
         self._wait_pending()
-        self.solver.step_rows(0, self.halo, False)
-        self.solver.step_rows(self.N - self.halo, self.halo, False)
+        self.solver.advance_rows(0, self.halo, depth, False)
+        self.solver.advance_rows(self.N - self.halo, self.halo, depth, False)
 
     def exchange(self):
         torch, s = self.torch, self.solver
@@ -216,9 +233,9 @@ class SlabSolver:
             e2.record(self.comm)
         self._pending = e2
 
-    def interior_update(self):
+    def interior_update(self, depth=1):
         # not ordered after the exchange: it runs while the halos travel
-        self.solver.step_rows(self.halo, self.N - 2 * self.halo, True)
+        self.solver.advance_rows(self.halo, self.N - 2 * self.halo, depth, True)
         self.solver.halo_mark_filled()
 
     def sync(self):

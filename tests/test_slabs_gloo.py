@@ -23,7 +23,7 @@ def _free_port():
 class NumpySlab:
     """Holds g = collide(f) on the slab plus ghost rows, like the HIP solver does."""
 
-    def __init__(self, dist, rank, world, cells, blocked, boundary, H, omega, surr):
+    def __init__(self, dist, rank, world, cells, blocked, boundary, H, omega, surr, last_depth=1):
         from latticeboltzmann_amd import slabs
         from oracle import lbm_numpy as onp
         self.onp, self.dist, self.slabs = onp, dist, slabs
@@ -41,6 +41,7 @@ class NumpySlab:
         self.blocked = blocked[rows].copy()
         self.omega = onp.make_omega(self.blocked, omega)
         self.fresh, self.hv, self.nxt = True, H, None
+        self.D = last_depth
 
     def _stream_reflect(self, g):
         f = g.copy()
@@ -66,6 +67,9 @@ class NumpySlab:
     def halo_valid(self):
         return self.hv
 
+    def last_depth(self):
+        return self.D
+
     def full_updates(self, k):
         for _ in range(k):
             if self.fresh:
@@ -76,9 +80,12 @@ class NumpySlab:
                 self.state = self._update()
                 self.hv -= 1
 
-    def edge_update(self):
-        assert self.hv == 1
-        self.nxt = self._update()  # the edge rows are what matters; the rest is reused below
+    def edge_update(self, depth=1):
+        assert self.hv == depth  # the jump uses up the ghost rows that are still valid
+        keep = self.state
+        for _ in range(depth):
+            self.state = self._update()
+        self.nxt, self.state = self.state, keep  # the edge rows are what matters; rest reused below
 
     def exchange(self):
         import torch
@@ -91,7 +98,7 @@ class NumpySlab:
                                            self.up, self.down):
             w.wait()
 
-    def interior_update(self):
+    def interior_update(self, depth=1):
         self.state, self.nxt, self.hv = self.nxt, None, self.H
 
     def owned_f(self):
@@ -100,7 +107,7 @@ class NumpySlab:
         return f[self.pt:self.pt + self.N]
 
 
-def _worker(rank, world, port, boundary, H, steps_list, G, M, outdir):
+def _worker(rank, world, port, boundary, H, steps_list, G, M, outdir, last_depth=1):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from latticeboltzmann_amd import slabs
@@ -112,7 +119,7 @@ def _worker(rank, world, port, boundary, H, steps_list, G, M, outdir):
         blocked = rng.random((G, M)) < 0.08
         cells = onp.perturbed_cells(G, M, seed=2, amp=0.05)
         surr = onp.ambient()
-        slab = NumpySlab(dist, rank, world, cells, blocked, boundary, H, 0.2, surr)
+        slab = NumpySlab(dist, rank, world, cells, blocked, boundary, H, 0.2, surr, last_depth)
         ref = cells.copy()
         for n in steps_list:
             slabs.advance(slab, n)
@@ -130,6 +137,18 @@ def test_slab_schedule_gloo(tmp_path, world, boundary, H):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(world, port, boundary, H, [1, 3, 4, 6, 1], 37, 21, str(tmp_path)),
+             nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.parametrize("world,boundary,H,D", [(2, "periodic", 4, 4), (3, "reference", 6, 4),
+                                                (2, "reference", 3, 6)])
+def test_slab_schedule_with_a_deep_last_jump(tmp_path, world, boundary, H, D):
+    """The cycle's split jump covers several updates (LDS kernel on the GPU): H - D full updates,
+    then D updates at once for the edge rows, exchange, the same jump for the interior."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, boundary, H, [1, 3, 4, 6, 1, 9, 2], 40, 21, str(tmp_path), D),
              nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 

@@ -162,3 +162,31 @@ def test_rccl_path_with_a_self_seam():
     code = _RCCL_SELF.format(root=ROOT, port=_free_port())
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and "rccl self-seam ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_advance_rows_checks_its_inputs():
+    """lbm_advance_rows: a row band may only jump as deep as the valid ghost rows behind it reach,
+    and all bands of one open update share the depth."""
+    from latticeboltzmann_amd import lb_hip_kernel as hk
+    from oracle import lbm_numpy as onp
+    N, M = 40, 128
+    s = hk.Solver(N, M, 0.3, boundary="periodic", halo=2, top_edge=hk.YEDGE_SEAM, bottom_edge=hk.YEDGE_SEAM)
+    s.set_surroundings(onp.ambient())
+    cells = onp.perturbed_cells(N + 4, M, seed=1)
+    s.upload_cells(cells, -2)
+    s.halo_mark_filled()
+    with pytest.raises(RuntimeError, match="stepped state"):
+        s.advance_rows(0, 4, 2, False)
+    s.fused_collide_stream(1)          # collide-only: consumes no ghost row
+    assert s.halo_valid == 2
+    with pytest.raises(RuntimeError, match="valid ghost rows"):
+        s.advance_rows(0, 4, 3, False)
+    with pytest.raises(RuntimeError, match="depth must be"):
+        s.advance_rows(0, 4, 7, False)
+    s.advance_rows(0, 4, 2, False)
+    with pytest.raises(RuntimeError, match="open update has depth 2"):
+        s.advance_rows(N - 4, 4, 1, False)
+    s.advance_rows(N - 4, 4, 2, False)
+    s.advance_rows(4, N - 8, 2, True)
+    assert s.steps_done == 3 and s.halo_valid == 0
+    s.close()
