@@ -230,6 +230,38 @@ def main():
         if not (np.isfinite(rho).all() and np.isfinite(u).all()):
             raise SystemExit("non-finite fields after the timed region")
         slab.close()
+        # BASELINE.md config 4 reads "halo 4, T = 4": the same slabs with the LDS kernel inside the
+        # halo cycle (one split depth-`halo` launch per cycle).  Reported beside the headline,
+        # never as `value` (the headline keeps the N = 1 kernel so that scaling compares like with like).
+        slab_tb = None
+        if args.depth == 1:
+            try:
+                d = min(args.halo, 6)
+                s4 = SlabSolver(rows * world, cols, onp.OMEGA, rank, world, boundary="periodic",
+                                halo=args.halo, device=local_rank, dist=dist, tb_max_depth=d)
+                s4.set_surroundings(surr)
+                s4.init_device_scene(100.0, (0.0, 0.1), amp=0.01, seed=0)
+                n4 = max(args.halo, (args.steps // args.halo) * args.halo)
+                s4.step(1 + 2 * args.halo)
+                s4.sync()
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s4.step(n4)
+                s4.sync()
+                torch.cuda.synchronize()
+                dist.barrier()
+                w4 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                                  device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(w4, op=dist.ReduceOp.MAX)
+                u4, rho4 = s4.read_moments(rows=(0, 8), cols=(0, 64))
+                s4.close()
+                slab_tb = {"depth": d, "halo": args.halo, "steps": n4, "unit": "GLUPS",
+                           "value": rows * cols * world * n4 / float(w4[0]) / 1e9,
+                           "ms_per_step": float(w4[0]) * 1e3 / n4,
+                           "finite": bool(np.isfinite(rho4).all() and np.isfinite(u4).all())}
+            except Exception as e:  # never let the extra line break the headline
+                slab_tb = {"error": repr(e)[:300]}
 
     if rank == 0:
         cells = rows * cols
@@ -258,6 +290,8 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * cells,
                          "traffic_source": tr.get("source") if tr else None},
         }
+        if world > 1 and slab_tb is not None:
+            line["slabs_temporal_blocking"] = slab_tb
         if world == 1:
             line["temporal_blocking"] = tb
             line["fp16_storage"] = fp16
