@@ -235,12 +235,20 @@ def main():
         # never as `value` (the headline keeps the N = 1 kernel so that scaling compares like with like).
         slab_tb = None
         if args.depth == 1:
+            d = min(args.halo, 6)
+            dev = f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu"
+            s4, err = None, None
             try:
-                d = min(args.halo, 6)
                 s4 = SlabSolver(rows * world, cols, onp.OMEGA, rank, world, boundary="periodic",
                                 halo=args.halo, device=local_rank, dist=dist, tb_max_depth=d)
                 s4.set_surroundings(surr)
                 s4.init_device_scene(100.0, (0.0, 0.1), amp=0.01, seed=0)
+            except Exception as e:  # never let the extra line break the headline ...
+                err = repr(e)[:300]
+            # ... nor leave the other ranks waiting in a collective: agree first
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 1:
                 n4 = max(args.halo, (args.steps // args.halo) * args.halo)
                 s4.step(1 + 2 * args.halo)
                 s4.sync()
@@ -251,17 +259,17 @@ def main():
                 s4.sync()
                 torch.cuda.synchronize()
                 dist.barrier()
-                w4 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
-                                  device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
+                w4 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
                 dist.all_reduce(w4, op=dist.ReduceOp.MAX)
                 u4, rho4 = s4.read_moments(rows=(0, 8), cols=(0, 64))
-                s4.close()
                 slab_tb = {"depth": d, "halo": args.halo, "steps": n4, "unit": "GLUPS",
                            "value": rows * cols * world * n4 / float(w4[0]) / 1e9,
                            "ms_per_step": float(w4[0]) * 1e3 / n4,
                            "finite": bool(np.isfinite(rho4).all() and np.isfinite(u4).all())}
-            except Exception as e:  # never let the extra line break the headline
-                slab_tb = {"error": repr(e)[:300]}
+            else:
+                slab_tb = {"error": err or "another rank failed to set up"}
+            if s4 is not None:
+                s4.close()
 
     if rank == 0:
         cells = rows * cols
