@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define LBM_ABI_VERSION 1
+#define LBM_ABI_VERSION 2 /* 2: lbm_config.omega is a double */
 
 typedef enum {
     LBM_OK = 0,
@@ -66,14 +66,18 @@ typedef struct {
     int32_t device;           /* HIP device ordinal */
     int32_t N;                /* rows owned by this solver */
     int32_t M;                /* columns */
-    float omega;              /* OMEGA, latticeboltzmann.py:80 (blocked cells use 1, :98) */
+    double omega;             /* OMEGA, latticeboltzmann.py:80, a Python float: the reference's omega
+                                 array (:98; blocked cells use 1) is float64 and `cells *= omega`
+                                 (:112) is a double product rounded once to float32.  The device
+                                 does the same (plain fp32 multiply when omega is a float32 value,
+                                 which gives the same bits). */
     int32_t inner_timesteps;  /* INNER_TIMESTEPS, latticeboltzmann.py:56: updates per outer step */
     int32_t boundary;         /* lbm_boundary */
     int32_t storage;          /* lbm_storage */
     int32_t halo;             /* ghost rows kept above and below (0 for a single domain) */
     int32_t top_edge;         /* lbm_yedge for row 0 */
     int32_t bottom_edge;      /* lbm_yedge for row N-1 */
-    int32_t reserved[5];
+    int32_t reserved[4];
 } lbm_config;
 
 typedef struct lbm_solver lbm_solver;

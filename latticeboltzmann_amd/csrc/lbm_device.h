@@ -39,9 +39,30 @@ struct Geom {
     long long rowStride;  // elements per row = Mb * CHUNK
     int top;         // YEDGE_* for y-1 at y == 0
     int bot;         // YEDGE_* for y+1 at y == N-1
-    float omega;
+    double omega;    // OMEGA (latticeboltzmann.py:80), a Python float = double
+    float omega_f;   // (float)omega
+    int omega_f32_exact;  // omega == (double)omega_f: the fp32 product below is the same number
     float surr[9];   // surroundings, reference k order
 };
+
+// The relaxation factor of the free cells as collide() wants it (wave-uniform, lives in SGPRs).
+struct Omega {
+    double d;
+    float f;
+    bool f32_exact;
+};
+__device__ __forceinline__ Omega omega_of(const Geom& geo) {
+    return Omega{geo.omega, geo.omega_f, geo.omega_f32_exact != 0};
+}
+// `cells *= omega` (latticeboltzmann.py:112).  The reference's omega is a FLOAT64 array
+// (np.where(blocked, np.array(1), np.array(OMEGA)), :98), so numpy multiplies the float32 cell by
+// it in double and rounds once to float32.  When omega is exactly representable in float32 the
+// double product of two 24-bit significands is exact (48 bits) and that single rounding is the
+// fp32 multiply's own: the plain v_mul_f32 gives the same bits (blocked cells: omega = 1).
+__device__ __forceinline__ float mul_omega(float v, bool blocked, const Omega& om) {
+    if (om.f32_exact) return v * (blocked ? 1.0f : om.f);
+    return (float)((double)v * (blocked ? 1.0 : om.d));
+}
 
 __host__ __device__ constexpr int slot_of(int k) { return 3 * (k % 3) + k / 3; }
 __host__ __device__ constexpr int dy_of(int k) { return k % 3 - 1; }
@@ -176,16 +197,26 @@ __device__ __forceinline__ void equilibrium(float u0, float u1, float p, float e
 }
 
 // --- collide (latticeboltzmann.py:107-113 with omega of :98) -----------------------------------
-__device__ __forceinline__ void collide(float a[Q], bool blocked, float omega_free) {
+__device__ __forceinline__ void collide(float a[Q], bool blocked, const Omega& om) {
     float p, u0, u1, eq[Q];
     moments(a, p, u0, u1);
     equilibrium(u0, u1, p, eq);
-    const float om = blocked ? 1.0f : omega_free;
+    if (om.f32_exact) {  // wave-uniform
+        const float o = blocked ? 1.0f : om.f;
 #pragma unroll
-    for (int k = 0; k < Q; k++) {
-        float v = a[k] - eq[k];
-        v = v * om;
-        a[k] = v + eq[k];
+        for (int k = 0; k < Q; k++) {
+            float v = a[k] - eq[k];
+            v = v * o;
+            a[k] = v + eq[k];
+        }
+    } else {
+        const double o = blocked ? 1.0 : om.d;
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            float v = a[k] - eq[k];
+            v = (float)((double)v * o);
+            a[k] = v + eq[k];
+        }
     }
 }
 
@@ -269,16 +300,26 @@ __device__ __forceinline__ void equilibrium2(f2 u0, f2 u1, f2 p, f2 eq[Q]) {
     eq[4] = pr * (1.0f - c);
 }
 
-__device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, float omega_free) {
+__device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, const Omega& om) {
     f2 p, u0, u1, eq[Q];
     moments2(a, p, u0, u1);
     equilibrium2(u0, u1, p, eq);
-    const f2 om = f2{b0 ? 1.0f : omega_free, b1 ? 1.0f : omega_free};
+    if (om.f32_exact) {  // wave-uniform
+        const f2 o = f2{b0 ? 1.0f : om.f, b1 ? 1.0f : om.f};
 #pragma unroll
-    for (int k = 0; k < Q; k++) {
-        f2 v = a[k] - eq[k];
-        v = v * om;
-        a[k] = v + eq[k];
+        for (int k = 0; k < Q; k++) {
+            f2 v = a[k] - eq[k];
+            v = v * o;
+            a[k] = v + eq[k];
+        }
+    } else {  // the reference's float64 omega: double product, one rounding (no packed f64 exists)
+        const double o0 = b0 ? 1.0 : om.d, o1 = b1 ? 1.0 : om.d;
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            f2 v = a[k] - eq[k];
+            v = f2{(float)((double)v.x * o0), (float)((double)v.y * o1)};
+            a[k] = v + eq[k];
+        }
     }
 }
 

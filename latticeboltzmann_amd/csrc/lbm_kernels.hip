@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void step_kernel(const T* __restrict__ gin, T*
     const uint64_t mrow = mask[(long long)(y + geo.G) * geo.Mb + xb];
     const bool blocked = (mrow >> lane) & 1ull;
     reflect(a, blocked);
-    collide(a, blocked, geo.omega);
+    collide(a, blocked, omega_of(geo));
 
     if (xb * LANES + lane < geo.M) {
         T* o = gout + (long long)(y + geo.G) * geo.rowStride + (long long)xb * CHUNK + lane;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void collide_kernel(T* __restrict__ f,
 #pragma unroll
     for (int k = 0; k < Q; k++) a[k] = ld(c + slot_of(k) * LANES);
     const bool blocked = (mask[(long long)(y + geo.G) * geo.Mb + xb] >> lane) & 1ull;
-    collide(a, blocked, geo.omega);
+    collide(a, blocked, omega_of(geo));
 #pragma unroll
     for (int k = 0; k < Q; k++) st(c + slot_of(k) * LANES, a[k]);
 }

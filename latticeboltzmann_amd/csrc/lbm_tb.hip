@@ -140,8 +140,8 @@ template <> struct LaneV<2> {
 };
 __device__ __forceinline__ void reflect_v(float* a, const bool* b) { reflect(a, b[0]); }
 __device__ __forceinline__ void reflect_v(f2* a, const bool* b) { reflect2(a, b[0], b[1]); }
-__device__ __forceinline__ void collide_v(float* a, const bool* b, float om) { collide(a, b[0], om); }
-__device__ __forceinline__ void collide_v(f2* a, const bool* b, float om) { collide2(a, b[0], b[1], om); }
+__device__ __forceinline__ void collide_v(float* a, const bool* b, const Omega& om) { collide(a, b[0], om); }
+__device__ __forceinline__ void collide_v(f2* a, const bool* b, const Omega& om) { collide2(a, b[0], b[1], om); }
 
 // Ring rows are addressed by ITERATION, not by row: in iteration i a stage writes its row into
 // ring row i mod depth of its level, and the next stage (two rows behind) finds rows q+1, q, q-1
@@ -171,7 +171,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     const int qlo = geo.top == YEDGE_DOMAIN ? 0 : -(1 << 28);  // rows that exist
     const int qhi = geo.bot == YEDGE_DOMAIN ? N : (1 << 28);
     const long long RS = geo.rowStride;
-    const float omega = geo.omega;
+    const Omega omega = omega_of(geo);
     const float su0 = geo.surr[0], su1 = geo.surr[1], su2 = geo.surr[2], su3 = geo.surr[3],
                 su4 = geo.surr[4], su5 = geo.surr[5], su6 = geo.surr[6], su7 = geo.surr[7],
                 su8 = geo.surr[8];

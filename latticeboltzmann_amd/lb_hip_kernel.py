@@ -15,6 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LBM_HIP_LIB", os.path.join(_HERE, "liblbm_hip.so"))  # env: dev experiments
 
+ABI_VERSION = 2  # include/lbm_hip.h LBM_ABI_VERSION
 BOUNDARY_REFERENCE, BOUNDARY_PERIODIC = 0, 1
 YEDGE_DOMAIN, YEDGE_SEAM = 0, 1
 STORE_F32, STORE_F16 = 0, 1
@@ -59,10 +60,10 @@ _PINNED = {}
 class lbm_config(ctypes.Structure):
     _fields_ = [
         ("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("N", ctypes.c_int32),
-        ("M", ctypes.c_int32), ("omega", ctypes.c_float), ("inner_timesteps", ctypes.c_int32),
+        ("M", ctypes.c_int32), ("omega", ctypes.c_double), ("inner_timesteps", ctypes.c_int32),
         ("boundary", ctypes.c_int32), ("storage", ctypes.c_int32), ("halo", ctypes.c_int32),
         ("top_edge", ctypes.c_int32), ("bottom_edge", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 5),
+        ("reserved", ctypes.c_int32 * 4),
     ]
 
 
@@ -131,8 +132,8 @@ def load_library(path=LIB_PATH):
         fn = getattr(L, name)  # AttributeError if the library does not export it
         fn.argtypes = argtypes
         fn.restype = restype
-    if L.lbm_abi_version() != 1:
-        raise RuntimeError(f"liblbm_hip.so ABI version {L.lbm_abi_version()} != 1")
+    if L.lbm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"liblbm_hip.so ABI version {L.lbm_abi_version()} != {ABI_VERSION}")
     _lib = L
     return L
 

@@ -87,9 +87,11 @@ def blocked_cylinder(N=400, M=800):
 
 
 def make_omega(blocked, omega_free=OMEGA):
-    """latticeboltzmann.py:98.  float32 so that `cells *= omega` stays float32."""
+    """latticeboltzmann.py:98, literally: an (N, M, 1) FLOAT64 array (np.array(1) is int64,
+    np.array(OMEGA) float64).  `cells *= omega` (:112) therefore multiplies float32 cells by a
+    float64 factor: numpy evaluates the product in double and rounds it once to float32."""
     return np.where(np.expand_dims(blocked, -1), np.array(1, ndmin=3),
-                    np.array(omega_free, ndmin=3)).astype(dtype)
+                    np.array(omega_free, ndmin=3))
 
 
 def initial_cells(blocked, insides):

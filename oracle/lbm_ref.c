@@ -18,6 +18,7 @@
  *   cells @ e_f            -> k-sequential multiply-add starting from 0 (products by 0,+-1 exact)
  *   u @ e_f.T              -> u0*e[k][0] + u1*e[k][1]
  *   np.nan_to_num          -> nan -> 0, +-inf -> +-FLT_MAX
+ *   cells *= omega         -> omega is float64 (:98): (float)((double)cell * omega), one rounding
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp -shared -fPIC (oracle/Makefile).
  */
 #include <float.h>
@@ -71,17 +72,19 @@ void lbmref_moments(const float* cells, long ncells, float* rho, float* u) {
 }
 
 /* moments + collide (latticeboltzmann.py:180-183,107-113), in place. */
-static void collide_all(float* cells, const uint8_t* blocked, long ncells, float omega_free) {
+static void collide_all(float* cells, const uint8_t* blocked, long ncells, double omega_free) {
 #pragma omp parallel for schedule(static)
     for (long c = 0; c < ncells; c++) {
         float* a = cells + 9 * c;
         float p, u0, u1, eq[9];
         cell_moments(a, &p, &u0, &u1);
         cell_equilibrium(u0, u1, p, eq);
-        float om = blocked[c] ? 1.0f : omega_free;
+        /* omega is a float64 array in the reference (:98): `cells *= omega` is a double product
+         * rounded once to float32 */
+        double om = blocked[c] ? 1.0 : omega_free;
         for (int k = 0; k < 9; k++) {
             float v = a[k] - eq[k];
-            v = v * om;
+            v = (float)((double)v * om);
             a[k] = v + eq[k];
         }
     }
@@ -122,7 +125,7 @@ static void stream_reflect(const float* g, float* f, const uint8_t* blocked, int
 
 /* Advance `cells` (N,M,9 float32, k fastest) by nsteps; `tmp` is scratch of the same size.
  * The result is left in `cells`. */
-void lbmref_run(float* cells, float* tmp, const uint8_t* blocked, int N, int M, float omega_free,
+void lbmref_run(float* cells, float* tmp, const uint8_t* blocked, int N, int M, double omega_free,
                 const float* surr, int boundary, int nsteps) {
     long ncells = (long)N * M;
     float *a = cells, *b = tmp;
@@ -135,7 +138,7 @@ void lbmref_run(float* cells, float* tmp, const uint8_t* blocked, int N, int M, 
 }
 
 /* The two halves, exposed so tests can check the post-collision state the HIP path stores. */
-void lbmref_collide(float* cells, const uint8_t* blocked, int N, int M, float omega_free) {
+void lbmref_collide(float* cells, const uint8_t* blocked, int N, int M, double omega_free) {
     collide_all(cells, blocked, (long)N * M, omega_free);
 }
 void lbmref_stream_reflect(const float* g, float* f, const uint8_t* blocked, int N, int M,

@@ -29,14 +29,14 @@ def lib():
         L = ctypes.CDLL(_SO)
         fp = ctypes.POINTER(ctypes.c_float)
         bp = ctypes.POINTER(ctypes.c_uint8)
-        L.lbmref_run.argtypes = [fp, fp, bp, ctypes.c_int, ctypes.c_int, ctypes.c_float, fp,
+        L.lbmref_run.argtypes = [fp, fp, bp, ctypes.c_int, ctypes.c_int, ctypes.c_double, fp,
                                  ctypes.c_int, ctypes.c_int]
         L.lbmref_run.restype = None
         L.lbmref_moments.argtypes = [fp, ctypes.c_long, fp, fp]
         L.lbmref_moments.restype = None
         L.lbmref_equilibrium.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_float, fp]
         L.lbmref_equilibrium.restype = None
-        L.lbmref_collide.argtypes = [fp, bp, ctypes.c_int, ctypes.c_int, ctypes.c_float]
+        L.lbmref_collide.argtypes = [fp, bp, ctypes.c_int, ctypes.c_int, ctypes.c_double]
         L.lbmref_collide.restype = None
         L.lbmref_stream_reflect.argtypes = [fp, fp, bp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int]
         L.lbmref_stream_reflect.restype = None
@@ -59,7 +59,7 @@ def run(cells, blocked, steps, omega_free, surroundings, boundary="reference"):
     blk = np.ascontiguousarray(blocked, dtype=np.uint8)
     surr = np.ascontiguousarray(surroundings, dtype=np.float32)
     tmp = np.empty_like(cells)
-    lib().lbmref_run(_f(cells), _f(tmp), _b(blk), N, M, np.float32(omega_free), _f(surr),
+    lib().lbmref_run(_f(cells), _f(tmp), _b(blk), N, M, float(omega_free), _f(surr),
                      BOUNDARY[boundary], steps)
     return cells
 
@@ -82,7 +82,7 @@ def equilibrium(u0, u1, p):
 def collide(cells, blocked, omega_free):
     N, M = cells.shape[:2]
     blk = np.ascontiguousarray(blocked, dtype=np.uint8)
-    lib().lbmref_collide(_f(cells), _b(blk), N, M, np.float32(omega_free))
+    lib().lbmref_collide(_f(cells), _b(blk), N, M, float(omega_free))
     return cells
 
 

@@ -5,10 +5,12 @@
                    (/root/reference/latticeboltzmann.py:40-41) for the reference's two scene images
                    yeet.png / yeet2.png, plus shape and popcount: the reference's own data, used
                    to pin obstacle-mask bit-exactness.
-  fields_*.npz     rho / u after 1, 10, 100, 1000 steps of oracle/lbm_numpy.py on small scenes.
-                   FIELD PARITY IS UNPINNED BY THE REFERENCE (it ships no golden fields and cannot
-                   run here): these vectors pin the oracle against itself over time (regressions,
-                   numpy upgrades) and pin the C restatement and the HIP path to it.
+  fields_*.npz     rho / u (and a sha256 of the cells) after 1, 10, 100, 1000 steps of THE
+                   REFERENCE'S OWN numpy lines, executed from /root/reference/latticeboltzmann.py
+                   by tests/golden/ref_extract.py (which reads that file at run time and stores
+                   none of it).  The oracle (numpy and C), and through it the HIP path, are pinned
+                   to these.  The periodic scene replaces the reference's stream() by np.roll (no
+                   reference counterpart); everything else in it is the reference's text too.
 """
 import hashlib
 import os
@@ -19,7 +21,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 from oracle import lbm_numpy as onp  # noqa: E402
+import ref_extract  # noqa: E402
 
 REF = "/root/reference"
 
@@ -36,14 +40,23 @@ def masks():
     np.savez_compressed(os.path.join(HERE, "masks.npz"), **out)
 
 
-def fields(tag, N, M, blocked, cells, omega, surr, boundary, checkpoints):
+def fields(tag, N, M, blocked, cells, omega, u_amb, boundary, checkpoints):
+    """cells=None: the reference's own initial state (latticeboltzmann.py:142)."""
+    ref = ref_extract.ReferenceNumpyPath(
+        blocked, {"OMEGA": omega, "u_ambient": u_amb}, cells=cells,
+        stream=onp.stream_periodic if boundary == "periodic" else None)
+    surr = ref.surroundings
+    assert np.array_equal(surr, onp.ambient(100, u_amb))
     out = {"blocked_bits": np.packbits(blocked), "shape": np.array([N, M]),
-           "omega": np.array(omega, np.float64), "surroundings": surr}
+           "omega": np.array(omega, np.float64), "surroundings": surr,
+           "source": np.array("reference text via tests/golden/ref_extract.py")}
+    if cells is not None:
+        out["cells_0"] = np.asarray(cells, np.float32)  # else: the reference's own initial state
     done = 0
     for c in checkpoints:
-        onp.run(cells, blocked, c - done, omega, surr, boundary)
+        cells = ref.step(c - done)
         done = c
-        u, p = onp.moments(cells)
+        u, p = ref.moments()
         out[f"rho_{c}"] = p.copy()
         out[f"u_{c}"] = u.copy()
         out[f"cells_sha_{c}"] = np.frombuffer(hashlib.sha256(cells.tobytes()).digest(), np.uint8)
@@ -53,21 +66,26 @@ def fields(tag, N, M, blocked, cells, omega, surr, boundary, checkpoints):
 
 def main():
     masks()
-    surr = onp.ambient()
     # 64 x 128 cylinder-like scene, reference boundaries, reference parameters
     N, M = 64, 128
     b = onp.blocked_cylinder(N, M)
-    fields("cyl64x128_reference", N, M, b, onp.initial_cells(b, surr), onp.OMEGA, surr, "reference",
-           (1, 10, 100, 1000))
-    # unsteady variant (latticeboltzmann.jl:27-29): OMEGA = 0.01, u = [0, 0.3]
-    surr3 = onp.ambient(100, [0, 0.3])
-    fields("cyl64x128_vortex", N, M, b, onp.initial_cells(b, surr3), 0.01, surr3, "reference",
-           (1, 10, 100, 1000))
+    fields("cyl64x128_reference", N, M, b, None, onp.OMEGA, [0, 0.1], "reference", (1, 10, 100, 1000))
+    # unsteady variant (latticeboltzmann.jl:27-29): OMEGA = 0.01, u = [0, 0.3]; long enough for
+    # the float64 omega of latticeboltzmann.py:98 to show (a float32 omega first differs after
+    # step 900 of this scene)
+    fields("cyl64x128_vortex", N, M, b, None, 0.01, [0, 0.3], "reference", (1, 10, 100, 1000, 2000))
+    # under-relaxed, strongly perturbed: the omega product matters from the first step
+    rng = np.random.default_rng(7)
+    N, M = 40, 72
+    b = onp.blocked_cylinder(N, M) | (rng.random((N, M)) < 0.03)
+    b[0] = b[-1] = False
+    fields("rand40x72_omega0p6", N, M, b, onp.perturbed_cells(N, M, seed=3, amp=0.05), 0.6, [0, 0.1],
+           "reference", (1, 10, 100, 400))
     # periodic, random obstacles, perturbed start
     rng = np.random.default_rng(0)
     N, M = 48, 80
     b = rng.random((N, M)) < 0.05
-    fields("rand48x80_periodic", N, M, b, onp.perturbed_cells(N, M, seed=0, amp=0.01), 0.1, surr,
+    fields("rand48x80_periodic", N, M, b, onp.perturbed_cells(N, M, seed=0, amp=0.01), 0.1, [0, 0.1],
            "periodic", (1, 10, 100))
 
 

@@ -29,7 +29,7 @@ def test_header_symbols_are_exported_and_bound():
     out = subprocess.check_output(["nm", "-D", "--defined-only", hk.LIB_PATH], text=True)
     exported = set(re.findall(r"\bT (lbm_[a-z_0-9]+)", out))
     assert set(declared) <= exported
-    assert L.lbm_abi_version() == 1
+    assert L.lbm_abi_version() == hk.ABI_VERSION == 2
 
 
 def test_config_struct_layout_matches_c(tmp_path):

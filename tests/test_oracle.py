@@ -102,18 +102,27 @@ def test_c_restatement_is_bit_identical_to_numpy(boundary):
     assert np.array_equal(ua, ub) and np.array_equal(pa, pb)
 
 
-@pytest.mark.parametrize("tag,boundary", [("cyl64x128_reference", "reference"),
-                                          ("cyl64x128_vortex", "reference"),
-                                          ("rand48x80_periodic", "periodic")])
-def test_golden_fields(tag, boundary):
+GOLDEN_FIELDS = [("cyl64x128_reference", "reference"), ("cyl64x128_vortex", "reference"),
+                 ("rand40x72_omega0p6", "reference"), ("rand48x80_periodic", "periodic")]
+
+
+def load_golden(tag):
+    """(z, N, M, blocked, surroundings, omega, initial cells) of a committed fixture."""
     z = np.load(os.path.join(GOLD, f"fields_{tag}.npz"))
     N, M = (int(v) for v in z["shape"])
     blocked = np.unpackbits(z["blocked_bits"])[:N * M].reshape(N, M).astype(bool)
     surr, omega = z["surroundings"], float(z["omega"])
-    if tag.startswith("cyl"):
-        cells = onp.initial_cells(blocked, surr)
-    else:
-        cells = onp.perturbed_cells(N, M, seed=0, amp=0.01)
+    cells = z["cells_0"].copy() if "cells_0" in z.files else onp.initial_cells(blocked, surr)
+    return z, N, M, blocked, surr, omega, cells
+
+
+@pytest.mark.parametrize("tag,boundary", GOLDEN_FIELDS)
+def test_golden_fields(tag, boundary):
+    """The restatements (numpy and C) against fields produced by the reference's OWN numpy lines
+    (tests/golden/ref_extract.py executed latticeboltzmann.py:16-35,80-95,98,107-123,142,180-183
+    from the reference file, in the order of latticeboltzmann.jl:107-120), bit for bit."""
+    z, N, M, blocked, surr, omega, cells = load_golden(tag)
+    assert str(z["source"]).startswith("reference text")
     ccells = cells.copy()
     done = 0
     for c in sorted(int(k.split("_")[1]) for k in z.files if k.startswith("rho_")):
@@ -125,6 +134,50 @@ def test_golden_fields(tag, boundary):
             assert np.array_equal(p, z[f"rho_{c}"]) and np.array_equal(u, z[f"u_{c}"])
             sha = np.frombuffer(hashlib.sha256(got.tobytes()).digest(), np.uint8)
             assert np.array_equal(sha, z[f"cells_sha_{c}"])
+
+
+def test_float64_omega_is_what_the_fixtures_pin():
+    """latticeboltzmann.py:98 builds omega as float64; a float32 omega (round 1's restatement)
+    must NOT reproduce the fixtures, or they would not pin that line."""
+    z, N, M, blocked, surr, omega, cells = load_golden("rand40x72_omega0p6")
+    assert onp.make_omega(blocked, omega).dtype == np.float64
+    om32 = onp.make_omega(blocked, omega).astype(np.float32)
+    for _ in range(10):
+        onp.step(cells, blocked, om32, surr, "reference")
+    assert not np.array_equal(onp.moments(cells)[1], z["rho_10"])
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/latticeboltzmann.py"),
+                    reason="build container only: the GPU box has no /root/reference")
+@pytest.mark.parametrize("omega,u_amb,steps", [(onp.OMEGA, [0, 0.1], 150), (0.01, [0, 0.3], 150),
+                                               (0.9, [0.02, 0.05], 80), (1.7, [0, 0.1], 40)])
+def test_live_reference_text_equals_the_restatement(omega, u_amb, steps):
+    """Executes the reference's own numpy lines (ref_extract) beside the restatement on scenes the
+    committed fixtures do not hold: same bits for cells, rho and u."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import ref_extract
+    rng = np.random.default_rng(11)
+    N, M = 37, 53
+    blocked = onp.blocked_cylinder(N, M) | (rng.random((N, M)) < 0.04)
+    start = onp.perturbed_cells(N, M, seed=2, amp=0.03, u=u_amb)
+    ref = ref_extract.ReferenceNumpyPath(blocked, {"OMEGA": omega, "u_ambient": u_amb}, cells=start)
+    assert ref.omega.dtype == np.float64 and ref.omega.shape == (N, M, 1)
+    assert np.array_equal(ref.omega, onp.make_omega(blocked, omega))
+    surr = onp.ambient(100, u_amb)
+    assert np.array_equal(ref.surroundings, surr)
+    a, c = start.copy(), start.copy()
+    with np.errstate(all="ignore"):
+        ref.step(steps)
+        onp.run(a, blocked, steps, omega, surr)
+    oc.run(c, blocked, steps, omega, surr)
+    assert np.array_equal(a, ref.cells, equal_nan=True) and np.array_equal(c, ref.cells, equal_nan=True)
+    ur, pr = ref.moments()
+    ua, pa = onp.moments(a)
+    assert np.array_equal(ua, ur, equal_nan=True) and np.array_equal(pa, pr, equal_nan=True)
+    # the reference's own initial state (latticeboltzmann.py:142) as well
+    ref0 = ref_extract.ReferenceNumpyPath(blocked, {"OMEGA": omega, "u_ambient": u_amb})
+    assert np.array_equal(ref0.cells, onp.initial_cells(blocked, surr))
 
 
 def test_mass_is_conserved_on_a_periodic_scene():

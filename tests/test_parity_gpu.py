@@ -223,18 +223,23 @@ def test_error_behaviour_of_the_abi():
 @pytest.mark.parametrize("T", [1, 6])
 @pytest.mark.parametrize("tag,boundary", [("cyl64x128_reference", "reference"),
                                           ("cyl64x128_vortex", "reference"),
+                                          ("rand40x72_omega0p6", "reference"),
                                           ("rand48x80_periodic", "periodic")])
 def test_committed_golden_fields(tag, boundary, T):
     """The HIP path against the committed fixtures alone (tests/golden/fields_*.npz: rho, u and a
-    sha256 of the cells after 1 / 10 / 100 / 1000 steps), plain kernel and LDS kernel."""
+    sha256 of the cells after 1 / 10 / 100 / 1000 (/ 2000) steps), plain kernel and LDS kernel.
+    The fixtures were produced by the reference's OWN numpy lines, executed from its file by
+    tests/golden/ref_extract.py -- this is the test that pins the device to the reference's text,
+    float64 omega (latticeboltzmann.py:98) included."""
     import hashlib
     import os
     from latticeboltzmann_amd.lb_hip_kernel import Solver
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"fields_{tag}.npz"))
+    assert str(z["source"]).startswith("reference text")
     N, M = (int(v) for v in z["shape"])
     blocked = np.unpackbits(z["blocked_bits"])[:N * M].reshape(N, M).astype(bool)
     surr, omega = z["surroundings"], float(z["omega"])
-    cells = onp.initial_cells(blocked, surr) if tag.startswith("cyl") else onp.perturbed_cells(N, M, seed=0, amp=0.01)
+    cells = z["cells_0"].copy() if "cells_0" in z.files else onp.initial_cells(blocked, surr)
     s = Solver(N, M, omega, boundary=boundary)
     s.set_tuning(T, 0)
     s.set_surroundings(surr)
@@ -248,4 +253,33 @@ def test_committed_golden_fields(tag, boundary, T):
         assert np.array_equal(p, z[f"rho_{c}"]) and np.array_equal(u, z[f"u_{c}"]), (tag, c)
         sha = np.frombuffer(hashlib.sha256(s.read_cells().tobytes()).digest(), np.uint8)
         assert np.array_equal(sha, z[f"cells_sha_{c}"]), (tag, c)
+    s.close()
+
+
+@pytest.mark.parametrize("T", [1, 2, 5])
+@pytest.mark.parametrize("omega", [0.5, 1.0, float(np.float32(0.3)), 0.3, 1e-14, 1.0 - 2.0 ** -40])
+def test_omega_is_a_double_as_in_the_reference(omega, T):
+    """latticeboltzmann.py:98 makes omega float64, so `cells *= omega` is a double product rounded
+    once.  The device takes the plain fp32 multiply when omega is a float32 value (same bits,
+    provably) and the double product otherwise: both against the oracle, bit for bit, on a scene
+    where the product decides the last bit from the first step on (large f - eq)."""
+    from latticeboltzmann_amd.lb_hip_kernel import Solver
+    N, M = 40, 200
+    rng = np.random.default_rng(5)
+    blocked = rng.random((N, M)) < 0.05
+    cells = onp.perturbed_cells(N, M, seed=4, amp=0.05)
+    cells *= (1 + 0.3 * (rng.random(cells.shape, dtype=np.float32) - 0.5))  # far from equilibrium
+    surr = onp.ambient()
+    s = Solver(N, M, omega, inner_timesteps=T, boundary="reference")
+    s.set_tuning(6, 0)
+    s.set_surroundings(surr)
+    s.upload_blocked(blocked)
+    s.upload_cells(cells)
+    ref = cells.copy()
+    for _ in range(3):
+        s.fused_collide_stream(1)
+        oc.run(ref, blocked, T, omega, surr)
+        assert np.array_equal(s.read_cells(), ref)
+    refn = onp.run(cells.copy(), blocked, 3 * T, omega, surr)
+    assert np.array_equal(refn, ref)
     s.close()

@@ -13,7 +13,8 @@ def main():
     tb_rows = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     tb_max = int(sys.argv[7]) if len(sys.argv) > 7 else 6
     dtype = np.float16 if (len(sys.argv) > 8 and sys.argv[8] == "f16") else np.float32
-    s = Solver(N, M, 1e-14, inner_timesteps=T, boundary=boundary, dtype=dtype)
+    omega = float(sys.argv[9]) if len(sys.argv) > 9 else 1e-14
+    s = Solver(N, M, omega, inner_timesteps=T, boundary=boundary, dtype=dtype)
     from oracle import lbm_numpy as onp
     s.set_surroundings(onp.ambient())
     s.set_tuning(tb_max, tb_rows)
@@ -23,7 +24,7 @@ def main():
     for rep in range(3):
         ms = s.fused_collide_stream_timed(steps)
         glups = N * M * steps * T / ms / 1e6
-        print(f"N={N} M={M} T={T} {boundary} {np.dtype(dtype).name}: {ms/steps:.3f} ms/outer  {glups:.2f} GLUPS  {glups*72/1000:.3f} TB/s(72B)  frac={glups*72/8000:.3f}", flush=True)
+        print(f"N={N} M={M} T={T} omega={omega} {boundary} {np.dtype(dtype).name}: {ms/steps:.3f} ms/outer  {glups:.2f} GLUPS  {glups*72/1000:.3f} TB/s(72B)  frac={glups*72/8000:.3f}", flush=True)
     u, rho = s.read_moments(rows=(0, 4), cols=(0, 8))
     print(rho[0, :4], u[0, :2])
 main()
