@@ -126,6 +126,19 @@ int lbm_advance(lbm_solver* s, int n_updates);
  * buffer uint8 (N, M, 3) as lb_cuda_kernel.cu:27-67,308-319 does; frame == NULL is the plain step,
  * as in latticeboltzmann.py:195-196.  The frame is complete after lbm_sync. */
 int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame);
+/* The same call for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.
+ * lbm_fused_collide_stream_display hipMallocs a device staging frame on its first call; this
+ * variant renders into a static device array inside the library instead (one copy of
+ * LBM_NOALLOC_FRAME_MAX_BYTES per GPU, resolved in lbm_create, held until the process ends) and
+ * calls no hipMalloc / hipFree / allocating routine.  Limits: N*M*3 <= LBM_NOALLOC_FRAME_MAX_BYTES
+ * (otherwise LBM_ERR_UNSUPPORTED, state untouched); `frame` must be page-locked host memory
+ * (lbm_host_alloc) or device memory (a pageable one is rejected: LBM_ERR_INVALID); NULL = plain
+ * step.  All solvers on one GPU share that GPU's array: calls whose frames are in flight at the
+ * same time on one GPU (different solvers / streams, no lbm_sync between) race; calls on one
+ * solver are ordered by its stream.  Results are identical to lbm_fused_collide_stream_display. */
+#define LBM_NOALLOC_FRAME_MAX_BYTES (32u << 20)
+int lbm_fused_collide_stream_display_noalloc(lbm_solver* s, uint8_t* frame);
 /* Tuning of the INNER_TIMESTEPS > 1 path (replaces the reference's per-GPU presets,
  * latticeboltzmann.py:55-71): deepest temporal-blocking launch (1..6; inner_timesteps is split
  * into balanced launches no deeper than this; 1 = plain kernel only; 0 = automatic, the default:

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "../../include/lbm_hip.h"
@@ -52,10 +53,36 @@ struct lbm_solver {
     void* staging;     // device staging for host-layout windows
     size_t staging_bytes;
     uint8_t* frame_dev;
+    void* scratch;     // this device's copy of the static scratch array (never freed)
     hipEvent_t ev0, ev1;
 };
 
 static const size_t STAGING_BYTES = 256ull << 20;
+
+// --- static device scratch of the allocation-free entry point --------------------------------
+// lbm_fused_collide_stream_display_noalloc renders its frame into this array instead of a
+// hipMalloc'ed staging buffer.  One copy per GPU, held until the process ends.  In host code the
+// array's NAME is only a handle for hipGetSymbolAddress: the device address is looked up once per
+// device (in lbm_create, with that device current) and kept in g_scratch_ptr / lbm_solver::scratch;
+// kernels and copies only ever see that pointer.
+static __device__ __align__(256) unsigned char scratch[LBM_NOALLOC_FRAME_MAX_BYTES];
+static const int MAX_DEVICES = 64;
+static void* g_scratch_ptr[MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static hipError_t scratch_for_device(int device, void** out) {
+    *out = nullptr;
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));  // the current device's copy
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 static int check(lbm_solver* s) {
     if (!s) return fail(LBM_ERR_INVALID, "null solver handle");
@@ -148,6 +175,7 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     if (rc == LBM_OK && (e = hipMalloc(&s->buf[1], s->buf_bytes)) != hipSuccess) bail(e, "hipMalloc(newcells)");
     if (rc == LBM_OK && (e = hipMalloc((void**)&s->mask, s->mask_bytes)) != hipSuccess) bail(e, "hipMalloc(mask)");
     if (rc == LBM_OK && (e = hipMalloc(&s->staging, s->staging_bytes)) != hipSuccess) bail(e, "hipMalloc(staging)");
+    if (rc == LBM_OK && (e = scratch_for_device(cfg->device, &s->scratch)) != hipSuccess) bail(e, "hipGetSymbolAddress(scratch)");
     if (rc == LBM_OK && (e = hipEventCreate(&s->ev0)) != hipSuccess) bail(e, "hipEventCreate");
     if (rc == LBM_OK && (e = hipEventCreate(&s->ev1)) != hipSuccess) bail(e, "hipEventCreate");
     // On the solver's own (non-blocking) stream: a hipMemset on the null stream returns before it
@@ -546,6 +574,40 @@ int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame) {
     HIPCHK(launch_observe(s->buf[s->cur], s->mask, s->geo, s->xmode, s->half, s->pulled, 0, s->geo.N, 0,
                           s->geo.M, nullptr, nullptr, nullptr, s->frame_dev, s->stream));
     HIPCHK(hipMemcpyAsync(frame, s->frame_dev, bytes, hipMemcpyDeviceToHost, s->stream));
+    return LBM_OK;
+}
+
+// The same step + frame without any allocation: the frame is rendered into the per-device static
+// scratch (looked up in lbm_create) and copied from there.  Nothing here calls hipMalloc / hipFree /
+// hipHostMalloc or any routine that does; a pageable `frame` is rejected because the runtime would
+// stage such a copy through buffers of its own.
+int lbm_fused_collide_stream_display_noalloc(lbm_solver* s, uint8_t* frame) {
+    ENTER(s);
+    const size_t bytes = (size_t)s->geo.N * s->geo.M * 3;
+    if (frame) {
+        if (bytes > (size_t)LBM_NOALLOC_FRAME_MAX_BYTES)
+            return fail(LBM_ERR_UNSUPPORTED,
+                        "a %d x %d frame is %zu bytes, more than the %u-byte static scratch of "
+                        "lbm_fused_collide_stream_display_noalloc (use lbm_fused_collide_stream_display)",
+                        s->geo.N, s->geo.M, bytes, (unsigned)LBM_NOALLOC_FRAME_MAX_BYTES);
+        if (!s->scratch) return fail(LBM_ERR_HIP, "the static scratch was not resolved on device %d", s->cfg.device);
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        const hipError_t pe = hipPointerGetAttributes(&at, frame);
+        if (pe != hipSuccess) (void)hipGetLastError();
+        if (pe != hipSuccess || at.type == hipMemoryTypeUnregistered)
+            return fail(LBM_ERR_INVALID, "frame must be page-locked host memory (lbm_host_alloc) or device "
+                                         "memory: a pageable destination makes the runtime stage the copy");
+        int rc = check_window(s, 0, s->geo.N, 0, s->geo.M);
+        if (rc) return rc;
+    }
+    int rc = lbm_fused_collide_stream(s, 1);
+    if (rc || !frame) return rc;
+    rc = check_window(s, 0, s->geo.N, 0, s->geo.M);
+    if (rc) return rc;
+    HIPCHK(launch_observe(s->buf[s->cur], s->mask, s->geo, s->xmode, s->half, s->pulled, 0, s->geo.N, 0,
+                          s->geo.M, nullptr, nullptr, nullptr, (uint8_t*)s->scratch, s->stream));
+    HIPCHK(hipMemcpyAsync(frame, s->scratch, bytes, hipMemcpyDeviceToHost, s->stream));
     return LBM_OK;
 }
 

@@ -31,8 +31,9 @@ SYMBOLS = [
     "lbm_sync", "lbm_steps_done", "lbm_read_cells", "lbm_read_moments", "lbm_read_blocked",
     "lbm_render", "lbm_halo_region", "lbm_mask_halo_region", "lbm_halo_valid",
     "lbm_halo_mark_filled", "lbm_set_tuning", "lbm_advance", "lbm_host_alloc",
-    "lbm_host_free", "lbm_advance_rows",
+    "lbm_host_free", "lbm_advance_rows", "lbm_fused_collide_stream_display_noalloc",
 ]
+NOALLOC_FRAME_MAX_BYTES = 32 << 20  # include/lbm_hip.h LBM_NOALLOC_FRAME_MAX_BYTES
 
 
 def pagelocked_empty(shape, dtype=np.uint8):
@@ -126,6 +127,7 @@ def load_library(path=LIB_PATH):
         "lbm_host_alloc": ([ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)], c_int),
         "lbm_host_free": ([ctypes.c_void_p], c_int),
         "lbm_advance_rows": ([H, c_int, c_int, c_int, c_int], c_int),
+        "lbm_fused_collide_stream_display_noalloc": ([H, bp], c_int),
     }
     assert set(protos) == set(SYMBOLS)
     for name, (argtypes, restype) in protos.items():
@@ -247,6 +249,14 @@ class Solver:
             assert frame.dtype == np.uint8 and frame.flags.c_contiguous
             assert frame.shape == (self.N, self.M, 3), frame.shape
         _check(self._L.lbm_fused_collide_stream_display(self._h, _bptr(frame)))
+
+    def fused_collide_stream_display_noalloc(self, frame=None):
+        """The same without any allocation in the library (static device scratch): `frame` must be
+        page-locked (pagelocked_empty) and at most NOALLOC_FRAME_MAX_BYTES."""
+        if frame is not None:
+            assert frame.dtype == np.uint8 and frame.flags.c_contiguous
+            assert frame.shape == (self.N, self.M, 3), frame.shape
+        _check(self._L.lbm_fused_collide_stream_display_noalloc(self._h, _bptr(frame)))
 
     def set_tuning(self, tb_max_depth=0, tb_rows=0):
         _check(self._L.lbm_set_tuning(self._h, tb_max_depth, tb_rows))
