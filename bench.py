@@ -108,7 +108,7 @@ def main():
     import torch
     from latticeboltzmann_amd import lb_hip_kernel as hk
     from latticeboltzmann_amd.slabs import SlabSolver
-    from oracle import lbm_numpy as onp
+    from latticeboltzmann_amd import latticeboltzmann as drv  # the product driver: OMEGA, ambient()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,14 +126,16 @@ def main():
         # on one GPU (halos staged through the host), never for a reported number
         backend = os.environ.get("LBM_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            from latticeboltzmann_amd.slabs import init_process_group_rccl
+            init_process_group_rccl(local_rank)  # RCCL's stream at high priority
         else:
             dist.init_process_group(backend)
 
     rows, cols = args.rows, args.cols
-    surr = onp.ambient()
+    surr = drv.ambient()
+    OMEGA = drv.OMEGA
     if world == 1:
-        solver = hk.Solver(rows, cols, onp.OMEGA, inner_timesteps=1, boundary="periodic",
+        solver = hk.Solver(rows, cols, OMEGA, inner_timesteps=1, boundary="periodic",
                            device=local_rank)
         solver.set_surroundings(surr)
         solver.init_equilibrium(100.0, (0.0, 0.1), amp=0.01, seed=0, row_offset=0, global_rows=rows)
@@ -164,8 +166,11 @@ def main():
         except Exception:
             pass
         tb = []
+        tr_all = traffic_per_launch() or {}
+        tb_traffic = {int(k.split(",")[1]): v for k, v in tr_all.get("temporal_blocking", {}).items()}
+        SIDE_LAUNCHES = 8  # side lines: at least this many timed launches whatever --steps says
         for T in (4, 5, 6):
-            s2 = hk.Solver(rows, cols, onp.OMEGA, inner_timesteps=T, boundary="periodic",
+            s2 = hk.Solver(rows, cols, OMEGA, inner_timesteps=T, boundary="periodic",
                            device=local_rank)
             s2.set_surroundings(surr)
             s2.init_equilibrium(100.0, (0.0, 0.1), amp=0.01, seed=0, row_offset=0, global_rows=rows)
@@ -173,37 +178,39 @@ def main():
                 s2.upload_blocked(scene)
             else:
                 s2.init_blocked_discs(64, 73, seed=1, global_rows=rows)
-            n_outer = max(1, args.steps // (2 * T))
-            s2.fused_collide_stream(2)
+            n_outer = max(SIDE_LAUNCHES, args.steps // (2 * T))
+            s2.fused_collide_stream(3)  # collide-only first update + 2 warm-up launches
             s2.sync()
             ms = s2.fused_collide_stream_timed(n_outer)
             u2, rho2 = s2.read_moments(rows=(0, 8), cols=(0, 64))
             ok = bool(np.isfinite(rho2).all() and np.isfinite(u2).all())
             s2.close()
             g = rows * cols * n_outer * T / ms / 1e6
-            tb.append({"inner_timesteps": T, "value": g, "unit": "GLUPS", "outer_steps": n_outer,
+            tt = tb_traffic.get(T) if (rows, cols) == (16384, 16384) else None
+            tb.append({"inner_timesteps": T, "value": g, "unit": "GLUPS", "launches": n_outer,
                        "ms_per_launch": ms / n_outer, "finite": ok,
+                       "traffic_bytes_per_update": tt["bytes_per_cell_update"] if tt else None,
                        "frac_of_72B_roofline": g * BYTES_PER_UPDATE / HBM_PEAK_GBS,
                        "workload": f"{rows}x{cols} periodic, {scene_name} (bounce-back), T={T}"})
         # BASELINE.json configs[4]'s storage variant on the headline grid: fp16 storage, fp32
         # arithmetic, 36 B per cell-update.  Reported beside the headline, never as `value`.
-        s3 = hk.Solver(rows, cols, onp.OMEGA, inner_timesteps=1, boundary="periodic",
+        s3 = hk.Solver(rows, cols, OMEGA, inner_timesteps=1, boundary="periodic",
                        device=local_rank, dtype=np.float16)
         s3.set_surroundings(surr)
         s3.init_equilibrium(100.0, (0.0, 0.1), amp=0.01, seed=0, row_offset=0, global_rows=rows)
         s3.fused_collide_stream(3)
         s3.sync()
-        n3 = max(1, args.steps // 4)
+        n3 = max(SIDE_LAUNCHES, args.steps // 4)
         ms3 = s3.fused_collide_stream_timed(n3)
         u3, rho3 = s3.read_moments(rows=(0, 8), cols=(0, 64))
         s3.close()
         g3 = rows * cols * n3 / ms3 / 1e6
-        fp16 = {"value": g3, "unit": "GLUPS", "steps": n3, "ms_per_launch": ms3 / n3,
+        fp16 = {"value": g3, "unit": "GLUPS", "launches": n3, "ms_per_launch": ms3 / n3,
                 "finite": bool(np.isfinite(rho3).all() and np.isfinite(u3).all()),
                 "hbm_GBps_at_36B": g3 * 36, "frac_of_36B_roofline": g3 * 36 / HBM_PEAK_GBS,
                 "workload": f"{rows}x{cols} periodic, fp16 storage / fp32 compute, T=1"}
     else:
-        slab = SlabSolver(rows * world, cols, onp.OMEGA, rank, world, boundary="periodic",
+        slab = SlabSolver(rows * world, cols, OMEGA, rank, world, boundary="periodic",
                           halo=args.halo, device=local_rank, dist=dist, tb_max_depth=args.depth)
         slab.set_surroundings(surr)
         slab.init_device_scene(100.0, (0.0, 0.1), amp=0.01, seed=0)
@@ -239,7 +246,7 @@ def main():
             dev = f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu"
             s4, err = None, None
             try:
-                s4 = SlabSolver(rows * world, cols, onp.OMEGA, rank, world, boundary="periodic",
+                s4 = SlabSolver(rows * world, cols, OMEGA, rank, world, boundary="periodic",
                                 halo=args.halo, device=local_rank, dist=dist, tb_max_depth=d)
                 s4.set_surroundings(surr)
                 s4.init_device_scene(100.0, (0.0, 0.1), amp=0.01, seed=0)
@@ -249,7 +256,7 @@ def main():
             ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok[0]) == 1:
-                n4 = max(args.halo, (args.steps // args.halo) * args.halo)
+                n4 = max(8 * args.halo, (args.steps // args.halo) * args.halo)  # >= 8 halo cycles
                 s4.step(1 + 2 * args.halo)
                 s4.sync()
                 dist.barrier()

@@ -18,6 +18,8 @@
  * Every function returns 0 on success and a nonzero lbm_status otherwise; lbm_last_error() gives
  * the message of the calling thread's last failure.  No exception, abort or exit crosses this ABI.
  * A handle is not thread-safe; different handles may be used from different threads.
+ * Every call makes the solver's device current while it runs and restores the calling thread's
+ * previous current device before it returns.
  * There is no CPU fallback: without a HIP device every call that needs one fails.
  */
 #ifndef LBM_HIP_H
@@ -57,7 +59,11 @@ typedef enum {
 
 typedef enum {
     LBM_STORE_F32 = 0,
-    LBM_STORE_F16 = 1 /* fp16 storage / fp32 compute, lb_cuda_kernel.cu:152-179 (half_enable) */
+    LBM_STORE_F16 = 1 /* fp16 storage / fp32 compute, lb_cuda_kernel.cu:152-179 (half_enable).
+                         Every time level is rounded through fp16, also between the updates of one
+                         temporal-blocking launch (as the reference rounds newcells on every inner
+                         timestep, lb_cuda_kernel.cu:292,361): results depend on the number of
+                         updates only, not on launch depth, tuning, grid size or slab count. */
 } lbm_storage;
 
 /* Replaces the #define block latticeboltzmann.py:126-132 and the launch geometry :187. */
@@ -154,7 +160,9 @@ int lbm_step_rows(lbm_solver* s, int row0, int nrows, int finish);
 /* The same with `depth` (1..6) updates in one launch: rows [row0, row0+nrows) jump `depth` time
  * levels into the other buffer (LDS kernel for depth > 1); their inputs, rows
  * [row0-depth, row0+nrows+depth), must be owned rows, valid ghost rows or beyond a domain edge.
- * All row ranges of one open update use the same depth; finish != 0 consumes `depth` ghost rows.
+ * Rows beyond a DOMAIN edge are never computable (ghost rows exist at seams only).
+ * All row ranges of one open update use the same depth; finish != 0 consumes `depth` ghost rows
+ * and is refused unless the ranges of the update cover all N owned rows.
  * With it the last `depth` updates of a halo cycle overlap with the exchange as well. */
 int lbm_advance_rows(lbm_solver* s, int row0, int nrows, int depth, int finish);
 /* Same as lbm_fused_collide_stream, bracketed by HIP events on the solver's stream; blocks and

@@ -50,6 +50,8 @@ struct lbm_solver {
     int ghost_valid;   // valid ghost rows beyond each seam
     bool open_update;  // lbm_advance_rows(finish = 0) has written part of the next state ...
     int open_depth;    // ... which lies this many updates ahead
+    int n_cov;         // owned-row intervals [a, b) the open update has written so far (merged,
+    int cov[16][2];    // sorted); finish is refused until they cover [0, N)
     void* staging;     // device staging for host-layout windows
     size_t staging_bytes;
     uint8_t* frame_dev;
@@ -84,18 +86,38 @@ static hipError_t scratch_for_device(int device, void** out) {
     return hipSuccess;
 }
 
-static int check(lbm_solver* s) {
+// Makes the solver's device current for the duration of one API call and puts the calling
+// thread's previous device back afterwards: a torch process that steps a solver on device d keeps
+// its own current device.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t enter(int device) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        if (prev == device) return hipSuccess;
+        e = hipSetDevice(device);
+        switched = e == hipSuccess && prev >= 0;
+        return e;
+    }
+    ~DeviceScope() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+static int check(lbm_solver* s, DeviceScope& scope) {
     if (!s) return fail(LBM_ERR_INVALID, "null solver handle");
-    HIPCHK(hipSetDevice(s->cfg.device));
+    HIPCHK(scope.enter(s->cfg.device));
     // HIP's last error is sticky and thread-wide: one left behind by other code in the process
     // (torch, another library) must not be reported by this call's launch checks
     (void)hipGetLastError();
     return LBM_OK;
 }
-#define ENTER(s)                      \
-    do {                              \
-        int rc_ = check(s);           \
-        if (rc_ != LBM_OK) return rc_; \
+#define ENTER(s)                          \
+    DeviceScope device_scope_;            \
+    do {                                  \
+        int rc_ = check(s, device_scope_); \
+        if (rc_ != LBM_OK) return rc_;    \
     } while (0)
 
 static size_t elem_size(const lbm_solver* s) { return s->half ? 2 : 4; }
@@ -135,7 +157,8 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     HIPCHK(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(LBM_ERR_INVALID, "device %d out of range (%d HIP devices)", cfg->device, ndev);
-    HIPCHK(hipSetDevice(cfg->device));
+    DeviceScope device_scope_;
+    HIPCHK(device_scope_.enter(cfg->device));
 
     lbm_solver* s = new (std::nothrow) lbm_solver();
     if (!s) return fail(LBM_ERR_NOMEM, "host allocation failed");
@@ -195,7 +218,8 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
 
 int lbm_destroy(lbm_solver* s) {
     if (!s) return LBM_OK;
-    (void)hipSetDevice(s->cfg.device);
+    DeviceScope device_scope_;
+    (void)device_scope_.enter(s->cfg.device);
     if (s->own_stream) (void)hipStreamSynchronize(s->own_stream);
     for (int i = 0; i < 2; i++)
         if (s->buf[i]) (void)hipFree(s->buf[i]);
@@ -420,11 +444,41 @@ int lbm_advance_rows(lbm_solver* s, int row0, int nrows, int depth, int finish) 
         return fail(LBM_ERR_UNSUPPORTED, "grids below 16 x 8 only take depth 1");
     if (s->open_update && depth != s->open_depth)
         return fail(LBM_ERR_INVALID, "the open update has depth %d, not %d", s->open_depth, depth);
-    // inputs at a seam must be valid ghost rows
-    if (nrows > 0 && ((seam_top(s) && row0 - depth < -s->ghost_valid) ||
-                      (seam_bot(s) && row0 + nrows + depth > g.N + s->ghost_valid)))
-        return fail(LBM_ERR_INVALID, "rows [%d, %d) at depth %d need more than the %d valid ghost rows",
-                    row0, row0 + nrows, depth, s->ghost_valid);
+    // Rows that may be computed: owned rows, plus -- at a seam only -- the ghost rows whose
+    // inputs [row-depth, row+depth] are still valid.  Beyond a domain (or wrap) edge there is
+    // nothing to compute and nothing allocated to read.
+    const int lo = seam_top(s) ? -(s->ghost_valid - depth) : 0;
+    const int hi = g.N + (seam_bot(s) ? s->ghost_valid - depth : 0);
+    if (nrows > 0 && (row0 < lo || row0 + nrows > hi))
+        return fail(LBM_ERR_INVALID, "rows [%d, %d) at depth %d: only [%d, %d) can be computed "
+                    "(%d valid ghost rows at a seam, none beyond a domain edge)",
+                    row0, row0 + nrows, depth, lo, hi, s->ghost_valid);
+    // owned rows this open update will have written after this call
+    int ncov = s->open_update ? s->n_cov : 0;
+    int cov[17][2];
+    memcpy(cov, s->cov, sizeof s->cov);
+    {
+        const int a = std::max(row0, 0), b = std::min(row0 + nrows, g.N);
+        if (a < b) {
+            int m = 0, na = a, nb = b;  // merge [a, b) into the sorted interval list
+            int out[17][2];
+            bool placed = false;
+            for (int i = 0; i < ncov; i++) {
+                if (cov[i][1] < na) { out[m][0] = cov[i][0]; out[m][1] = cov[i][1]; m++; }
+                else if (cov[i][0] > nb) {
+                    if (!placed) { out[m][0] = na; out[m][1] = nb; m++; placed = true; }
+                    out[m][0] = cov[i][0]; out[m][1] = cov[i][1]; m++;
+                } else { na = std::min(na, cov[i][0]); nb = std::max(nb, cov[i][1]); }
+            }
+            if (!placed) { out[m][0] = na; out[m][1] = nb; m++; }
+            if (m > 16) return fail(LBM_ERR_UNSUPPORTED, "more than 16 disjoint row ranges in one open update");
+            memcpy(cov, out, sizeof(int) * 2 * m);
+            ncov = m;
+        }
+    }
+    if (finish && !(ncov == 1 && cov[0][0] == 0 && cov[0][1] == g.N))
+        return fail(LBM_ERR_INVALID, "finish: the row ranges of this update do not cover all %d owned rows "
+                    "(uncovered rows would keep stale data)", g.N);
     if (depth == 1)
         HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, row0, nrows,
                            s->stream));
@@ -433,6 +487,8 @@ int lbm_advance_rows(lbm_solver* s, int row0, int nrows, int depth, int finish) 
                               nrows, s->tb_rows, s->stream));
     s->open_update = !finish;
     s->open_depth = depth;
+    s->n_cov = finish ? 0 : ncov;
+    memcpy(s->cov, cov, sizeof s->cov);
     if (finish) {
         s->cur ^= 1;
         s->steps += depth;

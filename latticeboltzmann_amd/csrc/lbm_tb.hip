@@ -348,6 +348,15 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
             }
         }
     };
+    // With fp16 storage every intermediate time level is rounded through half on its way into the
+    // ring, exactly as a store to / load from the fp16 field between two single updates would
+    // (the reference rounds `newcells` through half on every inner timestep too,
+    // lb_cuda_kernel.cu:292,361): a depth-T launch equals T single updates bit for bit for both
+    // storage types, so fp16 results do not depend on launch depth, tuning or slab count.
+    auto ring_value = [](float v) {
+        if (std::is_same<ST, __half>::value) return __half2float(__float2half_rn(v));
+        return v;
+    };
     auto to_lds = [&](auto xedge, auto ph, int q, const V* a, const bool* blocked) {
         constexpr int PH = decltype(ph)::value;
         if (XMODE != XMODE_PERIODIC && q == qhi) {
@@ -369,7 +378,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         for (int k = 0; k < Q; k++) {
 #pragma unroll
             for (int c = 0; c < CPL; c++)
-                *reinterpret_cast<float*>(wr_base + C::slot_off(slot_of(k), PH, 0) + 256 * c) = L::get(a[k], c);
+                *reinterpret_cast<float*>(wr_base + C::slot_off(slot_of(k), PH, 0) + 256 * c) = ring_value(L::get(a[k], c));
         }
 #pragma unroll
         for (int c = 0; c < CPL; c++) wr_flag[C::flag_off(PH, 0) + 64 * c] = blocked[c];
@@ -379,7 +388,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
                 if (slot_of(k) != 0) continue;
 #pragma unroll
                 for (int c = 0; c < CPL; c++)
-                    if (last_col[c]) *reinterpret_cast<float*>(wr_lev + C::edge_off(PH, 0)) = L::get(a[k], c);
+                    if (last_col[c]) *reinterpret_cast<float*>(wr_lev + C::edge_off(PH, 0)) = ring_value(L::get(a[k], c));
             }
         }
     };

@@ -22,6 +22,18 @@ import numpy as np
 from . import lb_hip_kernel as hk
 
 
+def init_process_group_rccl(device, **kw):
+    """torch.distributed over RCCL (backend "nccl") for the halo exchange, with RCCL's own stream
+    at high priority: its send/recv kernels must not queue behind the million-workgroup interior
+    launch they are meant to overlap with.  kw: init_method / rank / world_size when not taken
+    from the torchrun environment."""
+    import torch
+    import torch.distributed as dist
+    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"), pg_options=opts, **kw)
+    return dist
+
+
 def slab_rows(global_rows, world, rank):
     """Row range [lo, hi) of `rank`: equal slabs, the remainder spread over the first ranks."""
     q, r = divmod(global_rows, world)
@@ -128,7 +140,10 @@ class SlabSolver:
         if M < 8 or self.N < 16:  # the LDS kernel does not take grids this small
             self.tb_max_depth = 1
         self.compute = torch.cuda.Stream(device=self.device)
-        self.comm = torch.cuda.Stream(device=self.device)
+        # high priority: what runs on it (copies, event waits; RCCL's kernels run on RCCL's own
+        # stream, which bench.py also asks to be a high-priority one) must not queue behind the
+        # interior launch it overlaps with
+        self.comm = torch.cuda.Stream(device=self.device, priority=-1)
         self.solver.set_stream(self.compute.cuda_stream)
         self._tensors = {}
         self._fresh = True

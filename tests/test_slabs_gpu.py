@@ -127,8 +127,8 @@ from latticeboltzmann_amd.slabs import SlabSolver
 from oracle import lbm_numpy as onp
 from oracle import lbm_ref as oc
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                        device_id=torch.device("cuda:0"))
+from latticeboltzmann_amd.slabs import init_process_group_rccl
+init_process_group_rccl(0, init_method="tcp://127.0.0.1:{port}", rank=0, world_size=1)
 rng = np.random.default_rng(21)
 surr = onp.ambient()
 for G, M, halo, depth, steps in [(192, 320, 4, 1, (1, 3, 4, 9, 2, 16)), (64, 130, 1, 1, (1, 2, 5)),
@@ -187,6 +187,55 @@ def test_advance_rows_checks_its_inputs():
     with pytest.raises(RuntimeError, match="open update has depth 2"):
         s.advance_rows(N - 4, 4, 1, False)
     s.advance_rows(N - 4, 4, 2, False)
+    # finishing with owned rows uncovered would leave stale rows in the new state: refused
+    with pytest.raises(RuntimeError, match="do not cover"):
+        s.advance_rows(4, N - 9, 2, True)
     s.advance_rows(4, N - 8, 2, True)
     assert s.steps_done == 3 and s.halo_valid == 0
     s.close()
+    # ghost rows exist at seams only: beyond a DOMAIN edge nothing may be computed, whatever `halo`
+    # says (the kernel would read rows in front of the buffer)
+    s = hk.Solver(N, M, 0.3, boundary="reference", halo=3, top_edge=hk.YEDGE_DOMAIN,
+                  bottom_edge=hk.YEDGE_SEAM)
+    s.set_surroundings(onp.ambient())
+    s.upload_cells(onp.perturbed_cells(N + 6, M, seed=2), -3)
+    s.halo_mark_filled()
+    s.fused_collide_stream(1)
+    with pytest.raises(RuntimeError, match="can be computed"):
+        s.advance_rows(-1, 5, 1, False)
+    with pytest.raises(RuntimeError, match="can be computed"):
+        s.advance_rows(N - 4, 7, 1, False)     # only 2 ghost rows stay computable at depth 1
+    s.advance_rows(N - 4, 6, 1, False)         # owned rows + the 2 ghost rows that stay valid
+    s.advance_rows(0, N - 4, 1, True)
+    assert s.steps_done == 2 and s.halo_valid == 2
+    s.close()
+
+
+def test_bench_n2_rehearsal(tmp_path):
+    """bench.py's N > 1 branch (slab timing, the max-over-ranks all_reduce, the
+    `slabs_temporal_blocking` side line) run end to end before the driver runs it on an 8-GPU
+    node: a fresh child `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with
+    two ranks sharing this box's one GPU, halos staged through the host over gloo
+    (LBM_BENCH_BACKEND=gloo; RCCL refuses two ranks per device).  Checks the JSON contract, not
+    the speed."""
+    import json
+    import subprocess
+    env = dict(os.environ, LBM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "2048", "--cols", "2048",
+           "--steps", "8", "--warmup", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    (tmp_path / "bench_n2.log").write_text(r.stdout + "\n--- stderr ---\n" + r.stderr)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["warmup"] == 4 and d["scaling"] == "weak"
+    assert d["unit"] == "GLUPS" and d["value"] > 0 and d["higher_is_better"] is True
+    assert "gloo (rehearsal)" in d["config"]["decomposition"] and "2 y-slabs" in d["config"]["decomposition"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+    tb = d["slabs_temporal_blocking"]
+    assert "error" not in tb, tb
+    assert tb["finite"] is True and tb["depth"] == 4 and tb["halo"] == 4 and tb["value"] > 0
+    assert "cpu_baseline" not in d and "temporal_blocking" not in d

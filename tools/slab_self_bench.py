@@ -15,8 +15,8 @@ def main():
     halo = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     depth = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
-                            device_id=torch.device("cuda:0"))
+    from latticeboltzmann_amd.slabs import init_process_group_rccl
+    init_process_group_rccl(0, init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
     slab = SlabSolver(rows, cols, onp.OMEGA, 0, 1, boundary="periodic", halo=halo, device=0, dist=dist,
                       self_seam=True, tb_max_depth=depth)
     slab.set_surroundings(onp.ambient())
