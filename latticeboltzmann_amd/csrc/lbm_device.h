@@ -89,7 +89,13 @@ __device__ __forceinline__ void st_nt(__half* p, float v) {
 //              cell's own g_k(y, x)  (the reference's empty `-1:0` slices);
 //   periodic : wrapped source.
 // Seams (YEDGE_GHOST) read the ghost rows.  `y` must be wave-uniform.
-template <int XMODE, typename T>
+// NT: non-temporal loads (every stored value is read by exactly one cell per update: nothing to
+// keep in the caches).
+// Addressing: the three row bases are wave-uniform pointers (SGPR pairs) and a lane only carries
+// 32-bit element offsets, so every load is `global_load_dword v, voffset, s[base] offset:slot`
+// and a wave reaches its first load after a few dozen instructions.  All nine loads are issued
+// before the first use (two loops), so one s_waitcnt covers them.
+template <int XMODE, typename T, bool NT = false>
 __device__ __forceinline__ void pull(const T* __restrict__ g, const Geom& geo, int y, int xb,
                                      int lane, float t[Q]) {
     const int M = geo.M;
@@ -103,9 +109,9 @@ __device__ __forceinline__ void pull(const T* __restrict__ g, const Geom& geo, i
         xp = ob_p ? M - 1 : xp;
         ob_m = ob_p = false;
     }
-    const int off0 = (x >> 6) * CHUNK + (x & 63);
-    const int offm = ob_m ? off0 : (xm >> 6) * CHUNK + (xm & 63);
-    const int offp = ob_p ? off0 : (xp >> 6) * CHUNK + (xp & 63);
+    const unsigned off0 = (unsigned)((x >> 6) * CHUNK + (x & 63));
+    const unsigned offm = ob_m ? off0 : (unsigned)((xm >> 6) * CHUNK + (xm & 63));
+    const unsigned offp = ob_p ? off0 : (unsigned)((xp >> 6) * CHUNK + (xp & 63));
 
     int yu = y - 1, yd = y + 1;  // source rows for dy = +1 / dy = -1
     bool ob_u = false, ob_d = false;
@@ -115,21 +121,50 @@ __device__ __forceinline__ void pull(const T* __restrict__ g, const Geom& geo, i
     if (y == geo.N - 1 && geo.bot != YEDGE_GHOST) {
         if (geo.bot == YEDGE_WRAP) yd = 0; else { ob_d = true; yd = y; }
     }
+    // wave-uniform row bases; a source row outside the domain is the own row (yu / yd = y above)
     const T* r0 = g + (long long)(y + geo.G) * geo.rowStride;
     const T* ru = g + (long long)(yu + geo.G) * geo.rowStride;
     const T* rd = g + (long long)(yd + geo.G) * geo.rowStride;
+    // ... and then the own column too: the source is the cell's own value
+    const unsigned offm_u = ob_u ? off0 : offm, offp_u = ob_u ? off0 : offp;
+    const unsigned offm_d = ob_d ? off0 : offm, offp_d = ob_d ? off0 : offp;
 
+    float v[Q];
 #pragma unroll
     for (int k = 0; k < Q; k++) {
         const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
         const T* rb = dy == 1 ? ru : (dy == 0 ? r0 : rd);
-        const bool oy = dy == 1 ? ob_u : (dy == -1 ? ob_d : false);
-        const int off = dx == 1 ? offp : (dx == 0 ? off0 : offm);
-        const bool ox = dx == 1 ? ob_p : (dx == -1 ? ob_m : false);
-        const T* p = (ox || oy) ? (r0 + off0) : (rb + off);
-        float v = ld(p + sl);
-        const bool inlet = (dx == 1 && ox) || (dy == 1 && oy);
-        t[k] = inlet ? geo.surr[k] : v;
+        const unsigned off = dx == 0 ? off0
+                           : dy == 1 ? (dx == 1 ? offp_u : offm_u)
+                           : dy == -1 ? (dx == 1 ? offp_d : offm_d)
+                                      : (dx == 1 ? offp : offm);
+        const T* p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(rb + sl) +
+                                                (size_t)(off * (unsigned)sizeof(T)));
+        v[k] = NT ? ld_nt(p) : ld(p);
+    }
+    // Reference edge rule at the last column: the source column M of dx = -1 does not exist and
+    // the cell keeps its OWN value, own row included -- but the row bases above are wave-uniform.
+    // Only the wave that holds column M-1 pays for it: two more loads from the own row (dy = 0
+    // reads the own row anyway), chosen by the one lane concerned.
+    float own_m[3] = {0.0f, 0.0f, 0.0f};
+    if (XMODE != XMODE_PERIODIC && __any(ob_m)) {
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            if (dx_of(k) != -1 || dy_of(k) == 0) continue;
+            own_m[dy_of(k) + 1] = ld(r0 + slot_of(k) * LANES + off0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        const int dy = dy_of(k), dx = dx_of(k);
+        float w = v[k];
+        if (XMODE != XMODE_PERIODIC && dx == -1 && dy != 0) w = ob_m ? own_m[dy + 1] : w;
+        // hipcc would fold `inlet ? surr[k] : load` into ONE plain load from a selected (flat)
+        // pointer, which drops the non-temporal hint and puts the loads behind branches; an
+        // empty asm on the value keeps the load a load
+        if (NT) asm("" : "+v"(w));
+        const bool inlet = (dx == 1 && ob_p) || (dy == 1 && ob_u);
+        t[k] = inlet ? geo.surr[k] : w;
     }
 }
 
@@ -321,6 +356,27 @@ __device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, const Omega&
             a[k] = v + eq[k];
         }
     }
+}
+
+// Exact division of a tile index n < 2^31 by a run-time divisor d (blocks per row) without the
+// ~300-instruction 64-bit software division a wave would otherwise run before it can issue its
+// first load: q = (n * m) >> s with m = ceil(2^s / d), s = 31 + ceil(log2 d) (Granlund &
+// Montgomery); m < 2^33, so the product fits 64 bits.  All operands are wave-uniform (SALU).
+struct FastDiv {
+    unsigned long long m;
+    int s;
+    int d;
+};
+__host__ inline FastDiv make_fastdiv(int d) {
+    int l = 0;
+    while ((1ll << l) < d) l++;
+    const int s = 31 + l;
+    const unsigned long long m = (unsigned long long)((((unsigned __int128)1 << s) + (unsigned)d - 1) / (unsigned)d);
+    return FastDiv{m, s, d};
+}
+__device__ __forceinline__ void fastdivmod(unsigned n, const FastDiv& f, int& q, int& r) {
+    q = (int)(((unsigned long long)n * f.m) >> f.s);
+    r = (int)n - q * f.d;
 }
 
 // Bijective XCD-aware remap of a linear workgroup id: workgroups b, b+8, b+16, ... share an XCD

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 #include "../latticeboltzmann_amd/csrc/lbm_device.h"
@@ -13,7 +14,7 @@ using namespace lbm;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { F_NT_ST = 1, F_NT_LD = 2, F_NO_REMAP = 4, F_ROWS4 = 8, F_PERSIST = 16, F_TWO = 32, F_PK = 64, F_PKROW = 128, F_ROWXCD = 256, F_ROWXCD2 = 512, F_GROUPED = 1024 };
+enum { F_COPY9 = 8192, F_COPY9_ROWS = 16384, F_NOCOMPUTE = 32768, F_DPP = 2048, F_DPP_VEDGE = 4096, F_NT_ST = 1, F_NT_LD = 2, F_NO_REMAP = 4, F_ROWS4 = 8, F_PERSIST = 16, F_TWO = 32, F_PK = 64, F_PKROW = 128, F_ROWXCD = 256, F_ROWXCD2 = 512, F_GROUPED = 1024 };
 
 template <int FLAGS>
 __device__ __forceinline__ float ldx(const float* p) {
@@ -55,15 +56,78 @@ __device__ __forceinline__ void pullp(const float* __restrict__ g, const Geom& g
     }
 }
 
+// Aligned variant (SURVEY section 7 / VERDICT r1 item 3): all nine loads are the aligned 256-byte
+// slot planes of the own block; dx = +-1 come from a DPP wave shift by one lane, and the one lane
+// that falls off the wave takes ONE dword of the neighbouring block (wave-uniform address: a
+// scalar load; F_DPP_VEDGE: a single-lane vector load instead).
+template <int FLAGS>
+__device__ __forceinline__ void pullp_dpp(const float* __restrict__ g, const Geom& geo, int y, int xb, int lane, float t[Q]) {
+    const int xbm = xb + 1 == geo.Mb ? 0 : xb + 1;   // block of x+1 for lane 63
+    const int xbp = xb == 0 ? geo.Mb - 1 : xb - 1;   // block of x-1 for lane 0
+    const int yu = y == 0 ? geo.N - 1 : y - 1;
+    const int yd = y == geo.N - 1 ? 0 : y + 1;
+    const float* r0 = g + (long long)y * geo.rowStride;
+    const float* ru = g + (long long)yu * geo.rowStride;
+    const float* rd = g + (long long)yd * geo.rowStride;
+    float edge[Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
+        const float* rb = dy == 1 ? ru : (dy == 0 ? r0 : rd);
+        if (dx != 0) {
+            const float* pe = rb + (dx == 1 ? xbp * CHUNK + 63 : xbm * CHUNK) + sl;
+            if (FLAGS & F_DPP_VEDGE) {
+                edge[k] = 0.0f;
+                if (lane == (dx == 1 ? 0 : 63)) edge[k] = ldx<FLAGS>(pe);
+            } else {
+                edge[k] = *pe;  // uniform address
+            }
+        }
+        t[k] = ldx<FLAGS>(rb + xb * CHUNK + lane + sl);
+    }
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        const int dx = dx_of(k);
+        if (dx == 1)   // source lane-1: wave_shr:1, lane 0 keeps `old` = edge
+            t[k] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge[k]), __float_as_int(t[k]), 0x138, 0xf, 0xf, false));
+        else if (dx == -1)  // source lane+1: wave_shl:1, lane 63 keeps edge
+            t[k] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge[k]), __float_as_int(t[k]), 0x130, 0xf, 0xf, false));
+    }
+}
+
 template <int FLAGS>
 __device__ __forceinline__ void do_tile(const float* __restrict__ gin, float* __restrict__ gout,
                                         const uint64_t* __restrict__ mask, const Geom& geo, int y, int xb, int lane) {
     float a[Q];
-    pullp<FLAGS>(gin, geo, y, xb, lane, a);
+    if (FLAGS & (F_COPY9 | F_COPY9_ROWS)) {
+        // yardsticks in the kernel's own shape: nine aligned dword loads of the own block (from the
+        // own row, or from rows y-1 / y / y+1 as the pull does), no arithmetic, nine nt stores
+        const int yu = y == 0 ? geo.N - 1 : y - 1, yd = y == geo.N - 1 ? 0 : y + 1;
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            const int dy = dy_of(k);
+            const int ys = (FLAGS & F_COPY9_ROWS) ? (dy == 1 ? yu : (dy == 0 ? y : yd)) : y;
+            a[k] = ldx<FLAGS>(gin + (long long)ys * geo.rowStride + (long long)xb * CHUNK + lane + slot_of(k) * LANES);
+        }
+        float* o = gout + (long long)y * geo.rowStride + (long long)xb * CHUNK + lane;
+#pragma unroll
+        for (int k = 0; k < Q; k++) stx<FLAGS>(o + slot_of(k) * LANES, a[k]);
+        return;
+    }
+    if (FLAGS & F_NOCOMPUTE) {
+        // the real shifted pull, stored without reflect / collide
+        pullp<FLAGS>(gin, geo, y, xb, lane, a);
+        float* o = gout + (long long)y * geo.rowStride + (long long)xb * CHUNK + lane;
+#pragma unroll
+        for (int k = 0; k < Q; k++) stx<FLAGS>(o + slot_of(k) * LANES, a[k]);
+        return;
+    }
+    if (FLAGS & (F_DPP | F_DPP_VEDGE)) pullp_dpp<FLAGS>(gin, geo, y, xb, lane, a);
+    else pullp<FLAGS>(gin, geo, y, xb, lane, a);
     const uint64_t mrow = mask[(long long)y * geo.Mb + xb];
     const bool blocked = (mrow >> lane) & 1ull;
     reflect(a, blocked);
-    collide(a, blocked, geo.omega);
+    collide(a, blocked, omega_of(geo));
     if (FLAGS & F_GROUPED) {
         float* o = gout + (long long)y * geo.rowStride + (long long)xb * (3 * LANES) + lane;
 #pragma unroll
@@ -109,7 +173,7 @@ __global__ __launch_bounds__(256) void kvar(const float* __restrict__ gin, float
 #pragma unroll
         for (int k = 0; k < Q; k++) v[k] = f2{a[k], b[k]};
         reflect2(v, bl0, bl1);
-        collide2(v, bl0, bl1, geo.omega);
+        collide2(v, bl0, bl1, omega_of(geo));
         float* o0 = gout + (long long)y0 * geo.rowStride + (long long)xb0 * CHUNK + lane;
         float* o1 = gout + (long long)y1 * geo.rowStride + (long long)xb1 * CHUNK + lane;
 #pragma unroll
@@ -127,8 +191,8 @@ __global__ __launch_bounds__(256) void kvar(const float* __restrict__ gin, float
         pullp<FLAGS>(gin, geo, y + 1, xb, lane, b);
         const bool bl0 = (mask[(long long)y * geo.Mb + xb] >> lane) & 1ull;
         const bool bl1 = (mask[(long long)(y + 1) * geo.Mb + xb] >> lane) & 1ull;
-        reflect(a, bl0); collide(a, bl0, geo.omega);
-        reflect(b, bl1); collide(b, bl1, geo.omega);
+        reflect(a, bl0); collide(a, bl0, omega_of(geo));
+        reflect(b, bl1); collide(b, bl1, omega_of(geo));
         float* o = gout + (long long)y * geo.rowStride + (long long)xb * CHUNK + lane;
 #pragma unroll
         for (int k = 0; k < Q; k++) stx<FLAGS>(o + slot_of(k) * LANES, a[k]);
@@ -213,6 +277,11 @@ __global__ void initk(float* f, Geom geo) {
     f[i] = base[slot] * (1.0f + 0.01f * ((h & 0xffff) / 32768.0f - 1.0f));
 }
 
+__global__ void diffk(const unsigned* x, const unsigned* y, long long n, unsigned long long* cnt) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && x[i] != y[i]) atomicAdd(cnt, 1ull);
+}
+
 struct Var { const char* name; void (*fn)(const float*, float*, const uint64_t*, Geom); int div; bool persist; };
 
 template <int FLAGS> static Var mk(const char* n) {
@@ -225,7 +294,7 @@ int main(int argc, char** argv) {
     Geom geo{};
     geo.N = N; geo.M = M; geo.Mb = M / 64; geo.G = 0; const int padc = argc > 4 ? atoi(argv[4]) : 0;  // extra (unused) chunks per row: row stride experiment
     geo.rowStride = (long long)(geo.Mb + padc) * CHUNK;
-    geo.top = geo.bot = YEDGE_WRAP; geo.omega = 1e-14f;
+    geo.top = geo.bot = YEDGE_WRAP; geo.omega = 1e-14; geo.omega_f = 1e-14f; geo.omega_f32_exact = 0;
     const size_t bytes = (size_t)N * geo.rowStride * 4;
     float *a, *b; uint64_t* mask;
     CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes));
@@ -237,16 +306,38 @@ int main(int argc, char** argv) {
         mk<F_NO_REMAP>("no_remap"), mk<F_ROWS4>("rows4"), mk<F_ROWS4 | F_NT_ST>("rows4_ntst"),
         mk<F_TWO | F_NT_ST>("two_rows_ntst"), mk<F_PK | F_NT_ST>("pk_cols_ntst"), mk<F_PKROW | F_NT_ST>("pk_rows_ntst"),
         mk<F_PK>("pk_cols"), mk<F_GROUPED | F_NT_ST>("grouped_ntst"), mk<F_GROUPED>("grouped"), mk<F_ROWXCD | F_NT_ST>("rowxcd_ntst"), mk<F_ROWXCD2 | F_NT_ST>("rowxcd2_ntst"),
+        mk<F_NT_ST | F_NT_LD | F_ROWXCD2>("nt_both_rowxcd2"), mk<F_NT_ST | F_NT_LD | F_ROWXCD>("nt_both_rowxcd"),
+        mk<F_NT_ST | F_NT_LD | F_TWO>("nt_both_two_rows"), mk<F_NT_ST | F_NT_LD | F_DPP>("nt_both_dpp"),
+        mk<F_COPY9 | F_NT_ST | F_NT_LD>("copy9_nt_both"), mk<F_COPY9_ROWS | F_NT_ST | F_NT_LD>("copy9_3rows_nt_both"),
+        mk<F_COPY9 | F_NT_ST>("copy9_same_row"), mk<F_COPY9_ROWS | F_NT_ST>("copy9_three_rows"), mk<F_NOCOMPUTE | F_NT_ST>("pull_only"),
+        mk<F_DPP | F_NT_ST>("dpp_sedge_ntst"), mk<F_DPP_VEDGE | F_NT_ST>("dpp_vedge_ntst"), mk<F_DPP>("dpp_sedge"),
     };
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    std::vector<std::vector<float>> ms(vars.size());
     const long long ntiles = (long long)N * geo.Mb;
+    {   // every variant must produce the bits of the base variant (layout-changing ones excepted)
+        float* ref; unsigned long long* cnt;
+        CHECK(hipMalloc(&ref, bytes)); CHECK(hipMalloc(&cnt, 8));
+        hipLaunchKernelGGL(vars[0].fn, dim3((unsigned)(ntiles / 4)), dim3(256), 0, 0, (const float*)a, ref, (const uint64_t*)mask, geo);
+        for (size_t v = 1; v < vars.size(); v++) {
+            if (strstr(vars[v].name, "grouped") || strstr(vars[v].name, "copy9") || strstr(vars[v].name, "pull_only")) continue;
+            unsigned grid = vars[v].persist ? 256 * 8 : (unsigned)(ntiles / 4 / vars[v].div);
+            CHECK(hipMemset(cnt, 0, 8));
+            hipLaunchKernelGGL(vars[v].fn, dim3(grid), dim3(256), 0, 0, (const float*)a, b, (const uint64_t*)mask, geo);
+            const long long n = (long long)N * geo.rowStride;
+            hipLaunchKernelGGL(diffk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const unsigned*)ref, (const unsigned*)b, n, cnt);
+            unsigned long long h = 0; CHECK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost));
+            if (h) printf("VARIANT %s DIFFERS from base in %llu values\n", vars[v].name, h);
+        }
+        CHECK(hipFree(ref)); CHECK(hipFree(cnt));
+    }
+    std::vector<std::vector<float>> ms(vars.size());
+    const unsigned dyn_lds = argc > 6 ? (unsigned)atoi(argv[6]) : 0;  // residency cap for every variant
     for (int r = 0; r < rounds + 1; r++) {
         for (size_t v = 0; v < vars.size(); v++) {
             unsigned grid = vars[v].persist ? 256 * 8 : (unsigned)(ntiles / 4 / vars[v].div);
             CHECK(hipEventRecord(e0, 0));
             for (int i = 0; i < reps; i++) {
-                hipLaunchKernelGGL(vars[v].fn, dim3(grid), dim3(256), 0, 0, (const float*)a, b, (const uint64_t*)mask, geo);
+                hipLaunchKernelGGL(vars[v].fn, dim3(grid), dim3(256), dyn_lds, 0, (const float*)a, b, (const uint64_t*)mask, geo);
                 std::swap(a, b);
             }
             CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
@@ -311,6 +402,31 @@ int main(int argc, char** argv) {
             printf("offset %10zu B: %.3f ms  %.3f TB/s\n", offs[oi], t[t.size() / 2], (double)N * M * 72 / t[t.size() / 2] / 1e9);
         }
         CHECK(hipFree(big));
+    }
+    {   // occupancy sweep: dynamic LDS caps the resident workgroups per CU (160 KB / lds): how many
+        // bytes in flight per CU does the memory system like best?
+        const int ldsz[] = {0, 20 << 10, 23 << 10, 26 << 10, 32 << 10, 40 << 10, 53 << 10, 80 << 10};
+        for (int which = 0; which < 4; which++) {
+            for (size_t li = 0; li < sizeof ldsz / sizeof ldsz[0]; li++) {
+                std::vector<float> t;
+                for (int r = 0; r < rounds + 1; r++) {
+                    CHECK(hipEventRecord(e0, 0));
+                    for (int i = 0; i < reps; i++) {
+                        if (which == 0) hipLaunchKernelGGL(kvar<F_NT_ST>, dim3((unsigned)(ntiles / 4)), dim3(256), ldsz[li], 0, (const float*)a, b, (const uint64_t*)mask, geo);
+                        else if (which == 2) hipLaunchKernelGGL((kvar<F_NT_ST | F_NT_LD>), dim3((unsigned)(ntiles / 4)), dim3(256), ldsz[li], 0, (const float*)a, b, (const uint64_t*)mask, geo);
+                        else if (which == 3) hipLaunchKernelGGL((kvar<F_NT_ST | F_NT_LD | F_ROWXCD2>), dim3((unsigned)(ntiles / 4)), dim3(256), ldsz[li], 0, (const float*)a, b, (const uint64_t*)mask, geo);
+                        else hipLaunchKernelGGL((kvar<F_COPY9 | F_NT_ST>), dim3((unsigned)(ntiles / 4)), dim3(256), ldsz[li], 0, (const float*)a, b, (const uint64_t*)mask, geo);
+                        std::swap(a, b);
+                    }
+                    CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+                    float ms1; CHECK(hipEventElapsedTime(&ms1, e0, e1));
+                    if (r > 0) t.push_back(ms1 / reps);
+                }
+                std::sort(t.begin(), t.end());
+                printf("%s dynLDS %6d B (<= %d WG/CU): %.3f ms  %.3f TB/s\n", which == 0 ? "nt_store" : which == 1 ? "copy9   " : which == 2 ? "nt_both " : "nt_both_rowxcd2", ldsz[li],
+                       ldsz[li] ? std::min(8, (160 << 10) / ldsz[li]) : 8, t[t.size() / 2], (double)N * M * 72 / t[t.size() / 2] / 1e9);
+            }
+        }
     }
     float chk[4]; CHECK(hipMemcpy(chk, a + 12345 * 64, sizeof chk, hipMemcpyDeviceToHost));
     printf("check %g %g %g %g\n", chk[0], chk[1], chk[2], chk[3]);
