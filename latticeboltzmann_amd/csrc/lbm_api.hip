@@ -181,6 +181,7 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     g.omega = cfg->omega;
     g.omega_f = (float)cfg->omega;
     g.omega_f32_exact = (double)g.omega_f == cfg->omega;
+    g.omega_tiny = cfg->omega <= OMEGA_TINY_MAX && cfg->omega >= -OMEGA_TINY_MAX;  // false for NaN
     const size_t rows = (size_t)g.N + 2 * (size_t)g.G;
     s->buf_bytes = rows * (size_t)g.rowStride * elem_size(s);
     s->mask_bytes = rows * (size_t)g.Mb * sizeof(uint64_t);

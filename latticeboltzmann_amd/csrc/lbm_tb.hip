@@ -140,8 +140,8 @@ template <> struct LaneV<2> {
 };
 __device__ __forceinline__ void reflect_v(float* a, const bool* b) { reflect(a, b[0]); }
 __device__ __forceinline__ void reflect_v(f2* a, const bool* b) { reflect2(a, b[0], b[1]); }
-__device__ __forceinline__ void collide_v(float* a, const bool* b, const Omega& om) { collide(a, b[0], om); }
-__device__ __forceinline__ void collide_v(f2* a, const bool* b, const Omega& om) { collide2(a, b[0], b[1], om); }
+__device__ __forceinline__ void collide_v(float* a, const bool* b, const Omega& om, const bool* care) { collide(a, b[0], om, care[0]); }
+__device__ __forceinline__ void collide_v(f2* a, const bool* b, const Omega& om, const bool* care) { collide2(a, b[0], b[1], om, care[0], care[1]); }
 
 // Ring rows are addressed by ITERATION, not by row: in iteration i a stage writes its row into
 // ring row i mod depth of its level, and the next stage (two rows behind) finds rows q+1, q, q-1
@@ -187,7 +187,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     const int cx = 1 + j * (64 * CPL) + lane;  // ring-row index of cell 0; cell c is 64*c further
     int off0[CPL], offm[CPL], offp[CPL], mblk[CPL];
     unsigned mbit[CPL];
-    bool stored[CPL], ob_m[CPL], ob_p[CPL], last_col[CPL];
+    bool stored[CPL], ob_m[CPL], ob_p[CPL], last_col[CPL], care[CPL];
     bool any_xedge = false;
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
@@ -196,6 +196,10 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         if (XMODE == XMODE_PERIODIC) { xn = x % M; if (xn < 0) xn += M; }
         else xn = min(max(x, 0), M - 1);  // outside the domain: a valid address, never stored
         stored[c] = x >= xo && x < xo + C::SW && x < M;
+        // level s is only right s-1 columns inside the window (see the header): the columns
+        // beyond compute on stale ring contents and nobody reads what they produce
+        const int wc = j * (64 * CPL) + c * 64 + lane;
+        care[c] = wc >= s - 1 && wc < C::W - (s - 1);
         // x edge rule (reference mode only): source of dx = -1 / +1 outside the domain
         ob_m[c] = XMODE != XMODE_PERIODIC && x + 1 >= M;
         ob_p[c] = XMODE != XMODE_PERIODIC && x - 1 < 0;
@@ -420,7 +424,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
                 if (live(q)) {
                     inlet_fix(xedge, clampr(q), a);
                     reflect_v(a, blocked);
-                    collide_v(a, blocked, omega);
+                    collide_v(a, blocked, omega, care);
                     to_lds(xedge, ph, q, a, blocked);
                 }
                 q += 1;
@@ -440,7 +444,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
                     bool blocked[CPL];
                     gather(xedge, ph, q, a, blocked);
                     reflect_v(a, blocked);
-                    collide_v(a, blocked, omega);
+                    collide_v(a, blocked, omega, care);
                     if (s < T) {
                         to_lds(xedge, ph, q, a, blocked);
                     } else {

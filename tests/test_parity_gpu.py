@@ -283,3 +283,49 @@ def test_omega_is_a_double_as_in_the_reference(omega, T):
     refn = onp.run(cells.copy(), blocked, 3 * T, omega, surr)
     assert np.array_equal(refn, ref)
     s.close()
+
+
+@pytest.mark.parametrize("T", [1, 2, 5])
+@pytest.mark.parametrize("omega", [1e-14, 2.0 ** -34, 2.0 ** -34 * (1 + 2.0 ** -20), 0.0, -1e-14])
+def test_tiny_omega_shortcut_is_exact(omega, T):
+    """For |omega| <= 2^-34 (the reference's OMEGA = 1e-14) collide() returns eq without the
+    subtract / multiply / add wherever that is provably the same bits (lbm_device.h:
+    relax_is_identity) and falls back to the general path per wave elsewhere.  Scene: ordinary
+    cells next to everything the proof excludes -- negative populations, |u| > 0.29, zero density,
+    magnitudes beyond 2^+-100, non-finite cells, obstacles -- against the oracle, bit for bit."""
+    from latticeboltzmann_amd.lb_hip_kernel import Solver
+    N, M = 48, 704
+    rng = np.random.default_rng(17)
+    blocked = rng.random((N, M)) < 0.02
+    cells = onp.perturbed_cells(N, M, seed=9, amp=0.1)
+    cells[:, 64:128] = onp.getEquilibrium(                      # fast flow: c = 1.5 |u|^2 > 1/8
+        np.broadcast_to(np.float32([0.25, 0.3]), (N, 64, 2)), np.full((N, 64), 80, np.float32))
+    cells[:, 128:192] = onp.getEquilibrium(                     # just around the c = 1/8 threshold
+        np.stack([np.zeros((N, 64), np.float32),
+                  np.float32(0.2886) + np.float32(1e-4) * rng.standard_normal((N, 64)).astype(np.float32)], -1),
+        np.full((N, 64), 100, np.float32))
+    cells[:, 192:256] *= rng.choice(np.float32([-1, 1]), size=(N, 64, 9), p=[0.1, 0.9])  # negative f_k
+    cells[:, 256:320] *= np.float32(1e-32)                      # p < 2^-100
+    cells[:, 320:384] *= np.float32(1e31)                       # p > 2^100
+    cells[5:9, 384:448] = 0                                     # zero density
+    cells[20, 400] = [np.inf, 0, 0, 0, 1, 0, 0, 0, 0]
+    cells[21, 401] = [np.nan, 1, 1, 1, 1, 1, 1, 1, 1]
+    cells[:, 448:512, 0] = -0.0                                 # a negative zero is "not ordinary"
+    surr = onp.ambient()
+    s = Solver(N, M, omega, inner_timesteps=T, boundary="periodic")
+    s.set_tuning(6, 0)
+    s.set_surroundings(surr)
+    s.upload_blocked(blocked)
+    s.upload_cells(cells)
+    ref = cells.copy()
+    with np.errstate(all="ignore"):
+        for _ in range(3):
+            s.fused_collide_stream(1)
+            oc.run(ref, blocked, T, omega, surr, "periodic")
+            got = s.read_cells()
+            bad = np.argwhere(~((got == ref) | (np.isnan(got) & np.isnan(ref))))
+            assert bad.size == 0, f"omega={omega} T={T}: {len(bad)} mismatches, first {bad[:5].tolist()}"
+        refn = cells.copy()
+        onp.run(refn, blocked, 3 * T, omega, surr, "periodic")
+    assert np.array_equal(refn, ref, equal_nan=True)
+    s.close()

@@ -118,7 +118,8 @@ def test_two_slabs_with_temporal_blocking(tmp_path, boundary):
 
 
 _RCCL_SELF = r"""
-import sys
+import faulthandler, sys
+faulthandler.dump_traceback_later(120, exit=True)  # a hang names its line instead of being killed silently
 sys.path.insert(0, {root!r})
 import numpy as np
 import torch
@@ -160,7 +161,7 @@ def test_rccl_path_with_a_self_seam():
     interior update overlapped) — the code the multi-GPU bench runs, bit for bit against the oracle."""
     import subprocess
     code = _RCCL_SELF.format(root=ROOT, port=_free_port())
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=150)
     assert r.returncode == 0 and "rccl self-seam ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 

@@ -229,6 +229,10 @@ __global__ __launch_bounds__(256) void copy4(const v4f* __restrict__ in, v4f* __
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) __builtin_nontemporal_store(in[i], out + i);
 }
+__global__ __launch_bounds__(256) void copy4nt(const v4f* __restrict__ in, v4f* __restrict__ out, long long n4) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
 __global__ __launch_bounds__(256) void copy1(const float* __restrict__ in, float* __restrict__ out, long long n) {
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) __builtin_nontemporal_store(in[i], out + i);
@@ -294,7 +298,7 @@ int main(int argc, char** argv) {
     Geom geo{};
     geo.N = N; geo.M = M; geo.Mb = M / 64; geo.G = 0; const int padc = argc > 4 ? atoi(argv[4]) : 0;  // extra (unused) chunks per row: row stride experiment
     geo.rowStride = (long long)(geo.Mb + padc) * CHUNK;
-    geo.top = geo.bot = YEDGE_WRAP; geo.omega = 1e-14; geo.omega_f = 1e-14f; geo.omega_f32_exact = 0;
+    geo.top = geo.bot = YEDGE_WRAP; geo.omega = 1e-14; geo.omega_f = 1e-14f; geo.omega_f32_exact = 0; geo.omega_tiny = getenv("KB_TINY") ? 1 : 0;
     const size_t bytes = (size_t)N * geo.rowStride * 4;
     float *a, *b; uint64_t* mask;
     CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes));
@@ -307,7 +311,7 @@ int main(int argc, char** argv) {
         mk<F_TWO | F_NT_ST>("two_rows_ntst"), mk<F_PK | F_NT_ST>("pk_cols_ntst"), mk<F_PKROW | F_NT_ST>("pk_rows_ntst"),
         mk<F_PK>("pk_cols"), mk<F_GROUPED | F_NT_ST>("grouped_ntst"), mk<F_GROUPED>("grouped"), mk<F_ROWXCD | F_NT_ST>("rowxcd_ntst"), mk<F_ROWXCD2 | F_NT_ST>("rowxcd2_ntst"),
         mk<F_NT_ST | F_NT_LD | F_ROWXCD2>("nt_both_rowxcd2"), mk<F_NT_ST | F_NT_LD | F_ROWXCD>("nt_both_rowxcd"),
-        mk<F_NT_ST | F_NT_LD | F_TWO>("nt_both_two_rows"), mk<F_NT_ST | F_NT_LD | F_DPP>("nt_both_dpp"),
+        mk<F_NT_ST | F_NT_LD | F_TWO>("nt_both_two_rows"), mk<F_NT_ST | F_NT_LD | F_ROWS4>("nt_both_rows4"), mk<F_NT_ST | F_NT_LD | F_DPP>("nt_both_dpp"),
         mk<F_COPY9 | F_NT_ST | F_NT_LD>("copy9_nt_both"), mk<F_COPY9_ROWS | F_NT_ST | F_NT_LD>("copy9_3rows_nt_both"),
         mk<F_COPY9 | F_NT_ST>("copy9_same_row"), mk<F_COPY9_ROWS | F_NT_ST>("copy9_three_rows"), mk<F_NOCOMPUTE | F_NT_ST>("pull_only"),
         mk<F_DPP | F_NT_ST>("dpp_sedge_ntst"), mk<F_DPP_VEDGE | F_NT_ST>("dpp_vedge_ntst"), mk<F_DPP>("dpp_sedge"),
@@ -426,6 +430,23 @@ int main(int argc, char** argv) {
                 printf("%s dynLDS %6d B (<= %d WG/CU): %.3f ms  %.3f TB/s\n", which == 0 ? "nt_store" : which == 1 ? "copy9   " : which == 2 ? "nt_both " : "nt_both_rowxcd2", ldsz[li],
                        ldsz[li] ? std::min(8, (160 << 10) / ldsz[li]) : 8, t[t.size() / 2], (double)N * M * 72 / t[t.size() / 2] / 1e9);
             }
+        }
+    }
+    {   // the float4 streaming copy with non-temporal loads as well, under the same residency caps
+        const long long n = (long long)N * geo.rowStride;
+        const int ldsz[] = {0, 23 << 10, 32 << 10, 40 << 10, 53 << 10, 80 << 10};
+        for (size_t li = 0; li < sizeof ldsz / sizeof ldsz[0]; li++) {
+            std::vector<float> t;
+            for (int r = 0; r < rounds + 1; r++) {
+                CHECK(hipEventRecord(e0, 0));
+                for (int i = 0; i < reps; i++)
+                    hipLaunchKernelGGL(copy4nt, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), ldsz[li], 0, (const v4f*)a, (v4f*)b, n / 4);
+                CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+                float ms1; CHECK(hipEventElapsedTime(&ms1, e0, e1));
+                if (r > 0) t.push_back(ms1 / reps);
+            }
+            std::sort(t.begin(), t.end());
+            printf("copy float4 nt-load nt-store dynLDS %6d B: %.3f ms  %.3f TB/s\n", ldsz[li], t[t.size() / 2], 2.0 * n * 4 / t[t.size() / 2] / 1e9);
         }
     }
     float chk[4]; CHECK(hipMemcpy(chk, a + 12345 * 64, sizeof chk, hipMemcpyDeviceToHost));
