@@ -46,8 +46,17 @@ typedef enum {
 typedef enum {
     LBM_BOUNDARY_REFERENCE = 0, /* latticeboltzmann.py:115-120: column 0 / row 0 take surroundings[k]
                                    for dx / dy = +1; last column / last row keep their own value */
-    LBM_BOUNDARY_PERIODIC = 1   /* wrap-around in x and y (BASELINE.json configs 2-4; no reference
+    LBM_BOUNDARY_PERIODIC = 1,  /* wrap-around in x and y (BASELINE.json configs 2-4; no reference
                                    counterpart) */
+    LBM_BOUNDARY_CUDA_KERNEL = 2 /* compatibility mode, never the default: the semantics of the
+                                   reference's CUDA kernel where they differ from its numpy path
+                                   (lb_cuda_kernel.cu:215,232-233,286-306,322-331): all four sides
+                                   supply surroundings, density = sum + 0.0001f, the collide of row
+                                   r is gated by blocked[r-1][x], row 0 is never collided.  IEEE
+                                   fp32 in the kernel's operation order (the kernel itself is built
+                                   with --use_fast_math): PARITY-UNPINNED, no reference fixture
+                                   exists.  Single domain, one update per launch only; omega is
+                                   used as a float (`#define OMEGA ...f`). */
 } lbm_boundary;
 
 /* How a y-edge of THIS solver's row range is treated (y-slab decomposition). */

@@ -145,8 +145,12 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     if (cfg->N < 1 || cfg->M < 2) return fail(LBM_ERR_INVALID, "need N >= 1 and M >= 2");
     if (cfg->inner_timesteps < 1 || cfg->inner_timesteps > 64)
         return fail(LBM_ERR_INVALID, "inner_timesteps must be in [1, 64]");
-    if (cfg->boundary != LBM_BOUNDARY_REFERENCE && cfg->boundary != LBM_BOUNDARY_PERIODIC)
+    if (cfg->boundary != LBM_BOUNDARY_REFERENCE && cfg->boundary != LBM_BOUNDARY_PERIODIC &&
+        cfg->boundary != LBM_BOUNDARY_CUDA_KERNEL)
         return fail(LBM_ERR_INVALID, "unknown boundary %d", cfg->boundary);
+    if (cfg->boundary == LBM_BOUNDARY_CUDA_KERNEL &&
+        (cfg->halo != 0 || cfg->top_edge != LBM_YEDGE_DOMAIN || cfg->bottom_edge != LBM_YEDGE_DOMAIN))
+        return fail(LBM_ERR_UNSUPPORTED, "LBM_BOUNDARY_CUDA_KERNEL is single-domain only (no halo, no seams)");
     if (cfg->storage != LBM_STORE_F32 && cfg->storage != LBM_STORE_F16)
         return fail(LBM_ERR_INVALID, "unknown storage %d", cfg->storage);
     if (cfg->halo < 0 || cfg->halo > 64) return fail(LBM_ERR_INVALID, "halo must be in [0, 64]");
@@ -164,7 +168,8 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     if (!s) return fail(LBM_ERR_NOMEM, "host allocation failed");
     memset(s, 0, sizeof *s);
     s->cfg = *cfg;
-    s->xmode = cfg->boundary == LBM_BOUNDARY_PERIODIC ? XMODE_PERIODIC : XMODE_REFERENCE;
+    s->xmode = cfg->boundary == LBM_BOUNDARY_PERIODIC ? XMODE_PERIODIC
+             : cfg->boundary == LBM_BOUNDARY_CUDA_KERNEL ? XMODE_CUDA : XMODE_REFERENCE;
     s->half = cfg->storage == LBM_STORE_F16;
     s->T = cfg->inner_timesteps;
     s->tb_max = 0;  // automatic (depth_cap)
@@ -338,6 +343,7 @@ int lbm_halo_valid(lbm_solver* s, int* rows) {
 // where both are bound by launch latency alike (128 x 256: 8.3 GLUPS either way; from 400 x 800 on
 // the LDS kernel wins: 62 against 56 GLUPS).
 static int depth_cap(const lbm_solver* s) {
+    if (s->xmode == XMODE_CUDA) return 1;  // the compatibility mode only exists in the plain kernel
     if (s->tb_max > 0) return std::min(s->tb_max, TB_MAX_T);
     return (long long)s->geo.N * s->geo.M < TB_MIN_CELLS ? 1 : TB_DEFAULT_T;
 }
@@ -355,7 +361,7 @@ static int advance(lbm_solver* s, long long total, int max_depth) {
     const bool seam = seam_top(s) || seam_bot(s);
     while (total > 0) {
         if (!s->pulled) {
-            HIPCHK(launch_collide(s->buf[s->cur], s->mask, g, s->half, -g.G, g.N + 2 * g.G, s->stream));
+            HIPCHK(launch_collide(s->buf[s->cur], s->mask, g, s->xmode, s->half, -g.G, g.N + 2 * g.G, s->stream));
             s->pulled = true;
             s->steps++;
             total--;
@@ -369,6 +375,7 @@ static int advance(lbm_solver* s, long long total, int max_depth) {
         const long long nl = (total + max_depth - 1) / max_depth;
         int t = (int)((total + nl - 1) / nl);
         if (seam) t = std::min(t, s->ghost_valid);
+        if (s->xmode == XMODE_CUDA) t = 1;
         if (g.M < 8 || g.N < 16) t = 1;  // tiny domains: rows wrap at most once in the strip pipeline
         const int ext = seam ? s->ghost_valid - t : 0;
         const int r0 = seam_top(s) ? -ext : 0;
@@ -443,6 +450,8 @@ int lbm_advance_rows(lbm_solver* s, int row0, int nrows, int depth, int finish) 
     if (depth < 1 || depth > TB_MAX_T) return fail(LBM_ERR_INVALID, "depth must be in [1, %d]", TB_MAX_T);
     if (depth > 1 && (g.M < 8 || g.N < 16))
         return fail(LBM_ERR_UNSUPPORTED, "grids below 16 x 8 only take depth 1");
+    if (depth > 1 && s->xmode == XMODE_CUDA)
+        return fail(LBM_ERR_UNSUPPORTED, "LBM_BOUNDARY_CUDA_KERNEL only takes depth 1");
     if (s->open_update && depth != s->open_depth)
         return fail(LBM_ERR_INVALID, "the open update has depth %d, not %d", s->open_depth, depth);
     // Rows that may be computed: owned rows, plus -- at a seam only -- the ghost rows whose

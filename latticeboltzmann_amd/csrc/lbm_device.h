@@ -28,7 +28,7 @@ constexpr int LANES = 64;
 constexpr int Q = 9;
 constexpr int CHUNK = Q * LANES;  // elements per (row, xb) chunk
 
-enum : int { XMODE_REFERENCE = 0, XMODE_PERIODIC = 1 };
+enum : int { XMODE_REFERENCE = 0, XMODE_PERIODIC = 1, XMODE_CUDA = 2 };
 enum : int { YEDGE_DOMAIN = 0, YEDGE_WRAP = 1, YEDGE_GHOST = 2 };
 
 struct Geom {
@@ -412,6 +412,69 @@ __device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, const Omega&
             a[k] = v + eq[k];
         }
     }
+}
+
+// --- kernel-semantics compatibility mode (XMODE_CUDA) -----------------------------
+// What the reference's CUDA kernel computes where it differs from its numpy path, restated in IEEE
+// fp32 in the kernel's operation order (oracle: oracle/lbm_numpy.py cuda_kernel_step; PARITY-
+// UNPINNED: the reference holds no fixture for it and is built with --use_fast_math):
+// density = sum + 0.0001f, its own velocity sums and equilibrium form (lb_cuda_kernel.cu:293-300,
+// 323-331); a cell of row r is collided iff r >= 1 and blocked[r-1][x] is clear (:322 tests row y
+// for the cell of row y+1; :302-306 skips row 0); all four sides of the domain supply `surr`,
+// the side below the last row `surr` passed through the (gated) collide (:215,232-233,286-287).
+// a[] is in the reference's k order, k = 3*i + j = next.d[i][j].
+__device__ __forceinline__ void collide_cuda(float a[Q], float omega_f) {
+    const float s1 = (a[0] + a[1]) + a[2], s2 = (a[3] + a[4]) + a[5], s3 = (a[6] + a[7]) + a[8];
+    const float d = ((s1 + s2) + s3) + 0.0001f;
+    const float uy = (s3 - s1) / d;
+    const float ux = (((((a[2] + a[5]) + a[8]) - a[0]) - a[3]) - a[6]) / d;
+    const float c = 1.0f - 1.5f * (ux * ux + uy * uy);
+    const float W[3] = {1.0f / 36, 1.0f / 9, 4.0f / 9};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float eu = (float)(i - 1) * uy + (float)(j - 1) * ux;
+            const float wk = W[(i == 1) + (j == 1)];
+            const float eq = (d * wk) * (c + (3.0f * eu) * (1.0f + 1.5f * eu));
+            a[3 * i + j] = (a[3 * i + j] - eq) * omega_f + eq;
+        }
+    }
+}
+
+// Pull for XMODE_CUDA: a source outside the domain is surr[k]; below the last row it is surr
+// passed through the collide unless the cell above it (row N-1 of the source column) is blocked.
+template <typename T>
+__device__ __forceinline__ void pull_cuda(const T* __restrict__ g, const uint64_t* __restrict__ mask,
+                                          const Geom& geo, int y, int xb, int lane, float t[Q]) {
+    const int N = geo.N, M = geo.M;
+    int x = xb * LANES + lane;
+    x = x < M ? x : M - 1;
+    float csurr[Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) csurr[k] = geo.surr[k];
+    if (y == N - 1) collide_cuda(csurr, geo.omega_f);  // wave-uniform, last row only
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        const int dy = dy_of(k), dx = dx_of(k);
+        const int ys = y - dy, xs = x - dx;
+        const bool xin = xs >= 0 && xs < M, yin = ys >= 0 && ys < N;
+        const int yc = yin ? ys : y, xc = xin ? xs : x;  // a valid address in any case
+        const float v = ld(g + (long long)(yc + geo.G) * geo.rowStride + (xc >> 6) * CHUNK + (xc & 63) +
+                           slot_of(k) * LANES);
+        float out = geo.surr[k];
+        if (dy == -1) {  // the only direction that can look below the last row
+            const bool above_blocked = (mask[(long long)(N - 1 + geo.G) * geo.Mb + (xc >> 6)] >> (xc & 63)) & 1ull;
+            out = (ys == N && xin && !above_blocked) ? csurr[k] : out;
+        }
+        t[k] = (xin && yin) ? v : out;
+    }
+}
+// Is the cell (y, x) collided in XMODE_CUDA?
+__device__ __forceinline__ bool cuda_gate(const uint64_t* __restrict__ mask, const Geom& geo, int y,
+                                          int xb, int lane) {
+    if (y < 1) return false;
+    return !((mask[(long long)(y - 1 + geo.G) * geo.Mb + xb] >> lane) & 1ull);
 }
 
 // Exact division of a tile index n < 2^31 by a run-time divisor d (blocks per row) without the

@@ -32,11 +32,23 @@ __global__ __launch_bounds__(256) void step_kernel(const T* __restrict__ gin, T*
     const int y = row0 + yr;
 
     float a[Q];
-    pull<XMODE, T, LBM_T1_NT_LOADS>(gin, geo, y, xb, lane, a);
     const uint64_t mrow = mask[(long long)(y + geo.G) * geo.Mb + xb];
     const bool blocked = (mrow >> lane) & 1ull;
-    reflect(a, blocked);
-    collide(a, blocked, omega_of(geo));
+    if (XMODE == XMODE_CUDA) {  // kernel-semantics compatibility mode (never the default)
+        pull_cuda(gin, mask, geo, y, xb, lane, a);
+        reflect(a, blocked);
+        float b[Q];
+#pragma unroll
+        for (int k = 0; k < Q; k++) b[k] = a[k];
+        collide_cuda(b, geo.omega_f);
+        const bool gate = cuda_gate(mask, geo, y, xb, lane);
+#pragma unroll
+        for (int k = 0; k < Q; k++) a[k] = gate ? b[k] : a[k];
+    } else {
+        pull<XMODE, T, LBM_T1_NT_LOADS>(gin, geo, y, xb, lane, a);
+        reflect(a, blocked);
+        collide(a, blocked, omega_of(geo));
+    }
 
     if (xb * LANES + lane < geo.M) {
         T* o = gout + (long long)(y + geo.G) * geo.rowStride + (long long)xb * CHUNK + lane;
@@ -47,7 +59,7 @@ __global__ __launch_bounds__(256) void step_kernel(const T* __restrict__ gin, T*
 
 // f -> g = collide(f) in place over rows [row0, row0+nrows): the first half of the first update
 // after an upload (latticeboltzmann.py:180-183,107-113).
-template <typename T>
+template <typename T, bool CUDA_SEMANTICS = false>
 __global__ __launch_bounds__(256) void collide_kernel(T* __restrict__ f,
                                                       const uint64_t* __restrict__ mask, Geom geo,
                                                       int row0, int nrows) {
@@ -63,7 +75,12 @@ __global__ __launch_bounds__(256) void collide_kernel(T* __restrict__ f,
 #pragma unroll
     for (int k = 0; k < Q; k++) a[k] = ld(c + slot_of(k) * LANES);
     const bool blocked = (mask[(long long)(y + geo.G) * geo.Mb + xb] >> lane) & 1ull;
-    collide(a, blocked, omega_of(geo));
+    if (CUDA_SEMANTICS) {
+        if (!cuda_gate(mask, geo, y, xb, lane)) return;
+        collide_cuda(a, geo.omega_f);
+    } else {
+        collide(a, blocked, omega_of(geo));
+    }
 #pragma unroll
     for (int k = 0; k < Q; k++) st(c + slot_of(k) * LANES, a[k]);
 }
@@ -112,7 +129,8 @@ __global__ __launch_bounds__(256) void observe_kernel(const T* __restrict__ g,
     float a[Q];
     const bool blocked = (mask[(long long)(y + geo.G) * geo.Mb + xb] >> lane) & 1ull;
     if (PULLED) {
-        pull<XMODE>(g, geo, y, xb, lane, a);
+        if (XMODE == XMODE_CUDA) pull_cuda(g, mask, geo, y, xb, lane, a);
+        else pull<XMODE>(g, geo, y, xb, lane, a);
         reflect(a, blocked);
     } else {
         const int xc = x < geo.M ? x : geo.M - 1;
@@ -281,6 +299,9 @@ static hipError_t launch_step_t(const T* gin, T* gout, const uint64_t* mask, con
     if (xmode == XMODE_PERIODIC)
         hipLaunchKernelGGL((step_kernel<XMODE_PERIODIC, T>), dim3(nwg), dim3(256), lds, st, gin, gout,
                            mask, geo, row0, nrows, by_mb);
+    else if (xmode == XMODE_CUDA)
+        hipLaunchKernelGGL((step_kernel<XMODE_CUDA, T>), dim3(nwg), dim3(256), 0, st, gin, gout,
+                           mask, geo, row0, nrows, by_mb);
     else
         hipLaunchKernelGGL((step_kernel<XMODE_REFERENCE, T>), dim3(nwg), dim3(256), lds, st, gin, gout,
                            mask, geo, row0, nrows, by_mb);
@@ -293,10 +314,19 @@ hipError_t launch_step(const void* gin, void* gout, const uint64_t* mask, const 
                 : launch_step_t((const float*)gin, (float*)gout, mask, geo, xmode, row0, nrows, st);
 }
 
-hipError_t launch_collide(void* f, const uint64_t* mask, const Geom& geo, bool half, int row0,
-                          int nrows, hipStream_t st) {
+hipError_t launch_collide(void* f, const uint64_t* mask, const Geom& geo, int xmode, bool half,
+                          int row0, int nrows, hipStream_t st) {
     const unsigned nwg = tiles_to_wgs((long long)nrows * geo.Mb);
     if (nwg == 0) return hipSuccess;
+    if (xmode == XMODE_CUDA) {
+        if (half)
+            hipLaunchKernelGGL((collide_kernel<__half, true>), dim3(nwg), dim3(256), 0, st, (__half*)f, mask,
+                               geo, row0, nrows);
+        else
+            hipLaunchKernelGGL((collide_kernel<float, true>), dim3(nwg), dim3(256), 0, st, (float*)f, mask,
+                               geo, row0, nrows);
+        return hipGetLastError();
+    }
     if (half)
         hipLaunchKernelGGL(collide_kernel<__half>, dim3(nwg), dim3(256), 0, st, (__half*)f, mask, geo,
                            row0, nrows);
@@ -328,6 +358,7 @@ hipError_t launch_observe(const void* g, const uint64_t* mask, const Geom& geo, 
                                       rho, u, rgb, st);                                          \
     } while (0)
     if (xmode == XMODE_PERIODIC) { if (pulled) LBM_OBS(XMODE_PERIODIC, true); else LBM_OBS(XMODE_PERIODIC, false); }
+    else if (xmode == XMODE_CUDA) { if (pulled) LBM_OBS(XMODE_CUDA, true); else LBM_OBS(XMODE_CUDA, false); }
     else { if (pulled) LBM_OBS(XMODE_REFERENCE, true); else LBM_OBS(XMODE_REFERENCE, false); }
 #undef LBM_OBS
     return hipGetLastError();

@@ -16,10 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LBM_HIP_LIB", os.path.join(_HERE, "liblbm_hip.so"))  # env: dev experiments
 
 ABI_VERSION = 2  # include/lbm_hip.h LBM_ABI_VERSION
-BOUNDARY_REFERENCE, BOUNDARY_PERIODIC = 0, 1
+BOUNDARY_REFERENCE, BOUNDARY_PERIODIC, BOUNDARY_CUDA_KERNEL = 0, 1, 2
 YEDGE_DOMAIN, YEDGE_SEAM = 0, 1
 STORE_F32, STORE_F16 = 0, 1
-_BOUNDARIES = {"reference": BOUNDARY_REFERENCE, "periodic": BOUNDARY_PERIODIC}
+_BOUNDARIES = {"reference": BOUNDARY_REFERENCE, "periodic": BOUNDARY_PERIODIC,
+               "cuda_kernel": BOUNDARY_CUDA_KERNEL}
 _STORAGE = {np.dtype(np.float32): STORE_F32, np.dtype(np.float16): STORE_F16}
 
 # every symbol include/lbm_hip.h declares (tests check that the library exports all of them)

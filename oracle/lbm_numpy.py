@@ -175,3 +175,103 @@ def rel_linf(a, b):
     """Global-max-normalised L-inf: max|a-b| / max|b| (hard part 1)."""
     return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))) /
                  np.max(np.abs(b.astype(np.float64))))
+
+
+# ---------------------------------------------------------------------------------------------
+# Kernel-semantics compatibility mode (SURVEY.md 8 f3): what the reference's CUDA kernel computes
+# where it differs from the numpy path above.  PARITY-UNPINNED: the reference holds no fixture for
+# it and the kernel cannot be built or run here (nvcc, an NVIDIA GPU); it is compiled with
+# --use_fast_math (approximate division, FMA contraction, flush-to-zero), which no IEEE
+# restatement reproduces bit for bit.  This restates its STRUCTURE in IEEE float32, in the
+# kernel's own operation order, for INNER_TIMESTEPS = 1 (lb_cuda_kernel.cu:230-365):
+#   * density = sum + 0.0001f (:296); velocity by the kernel's sums (:293-300)
+#   * equilibrium d*w*(c + 3 eu (1 + 1.5 eu)), c = 1 - 1.5|u|^2 (:323-330)
+#   * the row that is collided in loop iteration y is row y+1, but the gate tests blocked[y][x]
+#     (:322 against :289): row r is collided iff r >= 1 and not blocked[r-1][x]; row 0 is never
+#     collided (:302-306 `continue` in front of the collide)
+#   * sources outside the domain are `surr` on all four sides (:215,232-233,286-287); the one below
+#     the last row is `surr` passed through the collide (gated by blocked[N-1][x]); edge lanes
+#     (x = -1, x = M) are never collided
+#   * stream and reflect as the numpy path (:336-357)
+# ---------------------------------------------------------------------------------------------
+def cuda_kernel_collide(a, omega_free=OMEGA):
+    """lb_cuda_kernel.cu:293-300,323-331 on cells a (..., 9), k = 3*i + j = next.d[i][j]."""
+    f32 = np.float32
+    a = np.asarray(a, dtype=f32)
+    s1 = (a[..., 0] + a[..., 1]) + a[..., 2]
+    s2 = (a[..., 3] + a[..., 4]) + a[..., 5]
+    s3 = (a[..., 6] + a[..., 7]) + a[..., 8]
+    d = ((s1 + s2) + s3) + f32(0.0001)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        uy = (s3 - s1) / d
+        ux = (((((a[..., 2] + a[..., 5]) + a[..., 8]) - a[..., 0]) - a[..., 3]) - a[..., 6]) / d
+    c = f32(1) - f32(1.5) * (ux * ux + uy * uy)
+    om = f32(omega_free)  # `#define OMEGA {OMEGA}f`, latticeboltzmann.py:129
+    out = np.empty_like(a)
+    for i in range(3):
+        for j in range(3):
+            eu = f32(i - 1) * uy + f32(j - 1) * ux
+            eq = (d * w[3 * i + j]) * (c + (f32(3) * eu) * (f32(1) + f32(1.5) * eu))
+            out[..., 3 * i + j] = (a[..., 3 * i + j] - eq) * om + eq
+    return out
+
+
+def cuda_kernel_gate(blocked):
+    """Which cells the kernel collides: row r >= 1 with blocked[r-1][x] clear."""
+    gate = np.ones(blocked.shape, bool)
+    gate[0] = False
+    gate[1:] &= ~blocked[:-1]
+    return gate
+
+
+def cuda_kernel_step(cells, blocked, surroundings, omega_free=OMEGA):
+    """One launch of the reference kernel with INNER_TIMESTEPS = 1 (structure only, see above):
+    returns the new cells."""
+    f32 = np.float32
+    N, M = blocked.shape
+    surr = np.asarray(surroundings, dtype=f32)
+    h = np.where(cuda_kernel_gate(blocked)[..., None], cuda_kernel_collide(cells, omega_free), cells)
+    P = np.empty((N + 2, M + 2, 9), f32)
+    P[:] = surr
+    P[1:-1, 1:-1] = h
+    P[-1, 1:-1] = np.where(blocked[-1][:, None], surr, cuda_kernel_collide(surr, omega_free))
+    out = np.empty((N, M, 9), f32)
+    for k, (dy, dx) in enumerate(e):
+        out[:, :, k] = P[1 - dy:N + 1 - dy, 1 - dx:M + 1 - dx, k]
+    reflect(out, blocked)
+    return out
+
+
+def cuda_kernel_step_loops(cells, blocked, surroundings, omega_free=OMEGA):
+    """The same launch as the kernel's own loop nest (one "thread" per column marching down the
+    rows with prev / curr / next, lb_cuda_kernel.cu:230-365, INNER_TIMESTEPS = 1), pure Python:
+    small grids only.  Pins cuda_kernel_step() against a literal reading of the kernel."""
+    f32 = np.float32
+    N, M = blocked.shape
+    surr = np.asarray(surroundings, dtype=f32)
+    new = np.empty((N, M, 9), f32)
+    lanes = range(-1, M + 1)  # x = -1 and x = M are edge lanes
+    prev = {x: surr.copy() for x in lanes}
+    curr = {x: surr.copy() for x in lanes}
+    for y in range(-1, N):
+        nxt = {}
+        for x in lanes:
+            edge = x < 0 or x >= M
+            n = surr.copy() if (edge or y >= N - 1) else cells[y + 1, x].astype(f32).copy()
+            if y != -1 and not edge and not blocked[y, x]:
+                n = cuda_kernel_collide(n, omega_free)
+            nxt[x] = n
+        if y == -1:
+            prev, curr = curr, nxt
+            continue
+        for x in range(M):
+            nc = np.empty(9, f32)
+            for j, src in enumerate((nxt, curr, prev)):   # d[i][j]: j = 0 next, 1 curr, 2 prev
+                nc[0 + j] = src[x + 1][0 + j]              # i = 0: __shfl_down (lane x+1)
+                nc[3 + j] = src[x][3 + j]                  # i = 1: own lane
+                nc[6 + j] = src[x - 1][6 + j]              # i = 2: __shfl_up (lane x-1)
+            if blocked[y, x]:
+                nc = nc[::-1].copy()
+            new[y, x] = nc
+        prev, curr = curr, nxt
+    return new
