@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -11,6 +12,10 @@
 #include "lbm_internal.h"
 
 using namespace lbm;
+
+#ifndef LBM_TB2_DEFAULT
+#define LBM_TB2_DEFAULT 0
+#endif
 
 static thread_local char g_err[512] = "";
 
@@ -342,6 +347,21 @@ int lbm_halo_valid(lbm_solver* s, int* rows) {
 // Deepest launch in use.  Automatic: TB_DEFAULT_T, but the plain kernel for grids below 2^17 cells,
 // where both are bound by launch latency alike (128 x 256: 8.3 GLUPS either way; from 400 x 800 on
 // the LDS kernel wins: 62 against 56 GLUPS).
+// Which LDS kernel runs a launch of depth t: lbm_tb2.hip (two levels per wave) where it is
+// instantiated, lbm_tb.hip otherwise.  LBM_TB2=0 in the environment forces the older kernel
+// (development comparisons).
+static hipError_t launch_deep(lbm_solver* s, int t, int r0, int nrows) {
+    static const int use2 = [] {
+        const char* e = getenv("LBM_TB2");
+        return e ? atoi(e) : LBM_TB2_DEFAULT;
+    }();
+    if (use2 && tb2_has_depth(t))
+        return launch_step_tb2(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, s->geo, s->xmode, s->half, t, r0,
+                               nrows, s->tb_rows, s->stream);
+    return launch_step_tb(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, s->geo, s->xmode, s->half, t, r0, nrows,
+                          s->tb_rows, s->stream);
+}
+
 static int depth_cap(const lbm_solver* s) {
     if (s->xmode == XMODE_CUDA) return 1;  // the compatibility mode only exists in the plain kernel
     if (s->tb_max > 0) return std::min(s->tb_max, TB_MAX_T);
@@ -384,8 +404,7 @@ static int advance(lbm_solver* s, long long total, int max_depth) {
             HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, r0,
                                r1 - r0, s->stream));
         else
-            HIPCHK(launch_step_tb(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, t,
-                                  r0, r1 - r0, s->tb_rows, s->stream));
+            HIPCHK(launch_deep(s, t, r0, r1 - r0));
         s->cur ^= 1;
         if (seam) s->ghost_valid -= t;
         s->steps += t;
@@ -493,8 +512,7 @@ int lbm_advance_rows(lbm_solver* s, int row0, int nrows, int depth, int finish) 
         HIPCHK(launch_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, row0, nrows,
                            s->stream));
     else
-        HIPCHK(launch_step_tb(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->half, depth, row0,
-                              nrows, s->tb_rows, s->stream));
+        HIPCHK(launch_deep(s, depth, row0, nrows));
     s->open_update = !finish;
     s->open_depth = depth;
     s->n_cov = finish ? 0 : ncov;

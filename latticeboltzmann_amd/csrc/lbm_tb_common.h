@@ -1,0 +1,66 @@
+// Shared pieces of the LDS temporal-blocking kernels (lbm_tb.hip: one level per wave and row;
+// lbm_tb2.hip: two levels per wave and row).
+#pragma once
+#include <type_traits>
+
+#include "lbm_internal.h"
+
+namespace lbm {
+
+
+
+// LDS image of one time level.  Each stored population is read by exactly one cell of the next
+// level: the dy = -1 populations (slots 0-2) of a row one iteration after they were written, the
+// dy = 0 ones (slots 3-5) two, the dy = +1 ones (slots 6-8) three iterations after.  So slots 0-2
+// need a ring of only DA = 2 rows, the others (and the flag bytes) 4: 124 instead of 148 bytes per
+// column and level.  The reference edge rule ("the last row / column keeps its own value",
+// latticeboltzmann.py:115-120) would read a cell's own slot 0-2 value two iterations late; instead
+//   - the stage that has just written the last domain row N-1 writes, one iteration later, a
+//     phantom row N whose slot 0-2 entries are row N-1's shifted by dx, so that the ordinary pull
+//     of row N-1 finds its own values there;
+//   - the lane of the last column M-1 also drops its slot-0 value into a 4-entry side ring
+//     (E_OFF), from which the x-edge code path takes it two iterations later.
+template <int T, int NB, int CPL, int MARG>
+struct TB {
+    static_assert(T - 1 <= MARG, "margin too small for this depth");
+    static_assert(NB % CPL == 0, "a lane owns CPL 64-column blocks");
+    static constexpr int DA = 2;                 // ring depth of the dy = -1 slots
+    static constexpr int W = NB * 64;            // window width (columns computed per stage)
+    static constexpr int SW = W - 2 * MARG;      // strip width (columns stored)
+    static constexpr int RW = W + 2;             // floats per slot row (+1 pad either side)
+    static constexpr int A_ROW = 3 * RW * 4;     // bytes per ring row of slots 0-2
+    static constexpr int B_ROW = 6 * RW * 4;     // bytes per ring row of slots 3-8
+    static constexpr int B_OFF = DA * A_ROW;
+    static constexpr int F_OFF = B_OFF + 4 * B_ROW;          // flag bytes, ring of 4 rows of RW bytes
+    static constexpr int E_OFF = (F_OFF + 4 * RW + 3) / 4 * 4;  // last column's slot 0, ring of 4 floats
+    static constexpr int LEVB = (E_OFF + 16 + 15) / 16 * 16;    // bytes per level
+    static constexpr int LDSB = (T - 1) * LEVB;
+    static constexpr int NW = T * NB / CPL;      // waves: one per (stage, CPL blocks)
+    // byte offset of population slot sl in the ring row written `age` iterations before phase ph
+    static constexpr int slot_off(int sl, int ph, int age) {
+        return sl < 3 ? ((ph - age) & (DA - 1)) * A_ROW + sl * RW * 4
+                      : B_OFF + ((ph - age) & 3) * B_ROW + (sl - 3) * RW * 4;
+    }
+    static constexpr int flag_off(int ph, int age) { return F_OFF + ((ph - age) & 3) * RW; }
+    static constexpr int edge_off(int ph, int age) { return E_OFF + ((ph - age) & 3) * 4; }
+};
+
+// value type of a lane: one cell (float) or two cells 64 columns apart (packed float2)
+template <int CPL> struct LaneV;
+template <> struct LaneV<1> {
+    using V = float;
+    static __device__ __forceinline__ V make(const float* v) { return v[0]; }
+    static __device__ __forceinline__ float get(V v, int) { return v; }
+};
+template <> struct LaneV<2> {
+    using V = f2;
+    static __device__ __forceinline__ V make(const float* v) { return f2{v[0], v[1]}; }
+    static __device__ __forceinline__ float get(V v, int c) { return c == 0 ? v.x : v.y; }
+};
+__device__ __forceinline__ void reflect_v(float* a, const bool* b) { reflect(a, b[0]); }
+__device__ __forceinline__ void reflect_v(f2* a, const bool* b) { reflect2(a, b[0], b[1]); }
+__device__ __forceinline__ void collide_v(float* a, const bool* b, const Omega& om, const bool* care) { collide(a, b[0], om, care[0]); }
+__device__ __forceinline__ void collide_v(f2* a, const bool* b, const Omega& om, const bool* care) { collide2(a, b[0], b[1], om, care[0], care[1]); }
+
+
+}  // namespace lbm
