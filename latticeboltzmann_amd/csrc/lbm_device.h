@@ -71,7 +71,8 @@ constexpr double OMEGA_TINY_MAX = 1.0 / 17179869184.0;  // 2^-34 = 5.8e-11 (the 
 // w (double, rounded to float; or the plain fp32 product) has |w| <= p * 2^-34 * (1 + 2^-23) + 2^-149
 // < 2^-26 * 0.010413 p <= 2^-26 eq_k < ulp(eq_k) / 4.  A float whose neighbours are at least
 // ulp/2 away (ulp/4 towards zero at a power of two) absorbs such a w: fl(w + eq_k) = eq_k.  QED
-// The test is wave-uniform (__all); a wave with a blocked cell (omega = 1 there) or a cell
+// The test is wave-uniform (__all); blocked cells (omega = 1: (a - eq) + eq, the product by 1 is
+// exact) are handled lane by lane inside the shortcut; a wave with a free cell
 // outside (1)-(3) -- zero density, negative or non-finite populations, |u| > 0.29 -- takes the
 // general path, so results are bit-identical for every input.
 // care = false: a lane whose result nobody reads (window-edge columns of the LDS kernel, which
@@ -81,7 +82,9 @@ __device__ __forceinline__ bool relax_is_identity(const float a[Q], float p, flo
     unsigned sg = __float_as_uint(a[0]);
 #pragma unroll
     for (int k = 1; k < Q; k++) sg |= __float_as_uint(a[k]);
-    const bool ok = !care || (!blocked && (int)sg >= 0 && p >= 7.888609052210118e-31f /* 2^-100 */ &&
+    // a blocked cell does not veto its wave: its relaxation factor is 1 and the caller computes
+    // (a - eq) + eq for it (exact in either product: v * 1 = v)
+    const bool ok = !care || blocked || ((int)sg >= 0 && p >= 7.888609052210118e-31f /* 2^-100 */ &&
                     p <= 1.2676506002282294e30f /* 2^100 */ && c <= 0.125f);
     return __all(ok);
 }
@@ -269,8 +272,16 @@ __device__ __forceinline__ void collide(float a[Q], bool blocked, const Omega& o
     moments(a, p, u0, u1);
     const float c = equilibrium(u0, u1, p, eq);
     if (om.tiny && relax_is_identity(a, p, c, blocked, care)) {  // wave-uniform
+        if (__any(blocked)) {  // obstacles are sparse: most waves skip this
 #pragma unroll
-        for (int k = 0; k < Q; k++) a[k] = eq[k];
+            for (int k = 0; k < Q; k++) {
+                const float v = a[k] - eq[k];
+                a[k] = blocked ? v + eq[k] : eq[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < Q; k++) a[k] = eq[k];
+        }
         return;
     }
     if (om.f32_exact) {  // wave-uniform
@@ -380,8 +391,8 @@ __device__ __forceinline__ bool relax_is_identity2(const f2 a[Q], f2 p, f2 c, bo
 #pragma unroll
     for (int k = 1; k < Q; k++) { sx |= __float_as_uint(a[k].x); sy |= __float_as_uint(a[k].y); }
     const float lo = 7.888609052210118e-31f, hi = 1.2676506002282294e30f;
-    const bool ok0 = !care0 || (!b0 && (int)sx >= 0 && p.x >= lo && p.x <= hi && c.x <= 0.125f);
-    const bool ok1 = !care1 || (!b1 && (int)sy >= 0 && p.y >= lo && p.y <= hi && c.y <= 0.125f);
+    const bool ok0 = !care0 || b0 || ((int)sx >= 0 && p.x >= lo && p.x <= hi && c.x <= 0.125f);
+    const bool ok1 = !care1 || b1 || ((int)sy >= 0 && p.y >= lo && p.y <= hi && c.y <= 0.125f);
     return __all(ok0 && ok1);
 }
 
@@ -391,8 +402,16 @@ __device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, const Omega&
     moments2(a, p, u0, u1);
     const f2 c = equilibrium2(u0, u1, p, eq);
     if (om.tiny && relax_is_identity2(a, p, c, b0, b1, care0, care1)) {  // wave-uniform
+        if (__any(b0 || b1)) {  // obstacles are sparse: most waves skip this
 #pragma unroll
-        for (int k = 0; k < Q; k++) a[k] = eq[k];
+            for (int k = 0; k < Q; k++) {
+                const f2 v = (a[k] - eq[k]) + eq[k];  // blocked cells: omega = 1
+                a[k] = f2{b0 ? v.x : eq[k].x, b1 ? v.y : eq[k].y};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < Q; k++) a[k] = eq[k];
+        }
         return;
     }
     if (om.f32_exact) {  // wave-uniform
