@@ -275,3 +275,29 @@ def cuda_kernel_step_loops(cells, blocked, surroundings, omega_free=OMEGA):
             new[y, x] = nc
         prev, curr = curr, nxt
     return new
+
+
+def cuda_kernel_frame(u, p, blocked):
+    """The RGB frame of the reference's CUDA kernel (lb_cuda_kernel.cu:27-67 hsv_to_rgb, :308-319):
+    h = atan2(uy, ux) + PI with the kernel's `uy` = column (x) and `ux` = row (y) component,
+    s = saturate(1000 |u|), v = saturate(density), black where blocked; float32 in the kernel's
+    operation order, round-to-nearest * 255.  u (N, M, 2) [row, col], p (N, M) -> uint8 (N, M, 3).
+    PARITY-UNPINNED: the reference holds no frame fixture (its videos are not in the tree) and the
+    kernel uses --use_fast_math (atan2f / sqrtf approximations): the device frame is compared to
+    this with a tolerance of one count per channel."""
+    f32 = np.float32
+    PI = f32(3.141592653589)
+    u0, u1 = u[..., 0], u[..., 1]
+    h = (np.arctan2(u1, u0).astype(f32) + PI).astype(f32)
+    s = np.clip(f32(1000) * np.sqrt(u0 * u0 + u1 * u1), 0, 1).astype(f32)
+    v = np.clip(p, 0, 1).astype(f32)
+    h, s, v = (np.where(blocked, f32(0), a) for a in (h, s, v))
+    f = (h / (PI / f32(3))).astype(f32)
+    hi = np.floor(f)
+    f = f - hi
+    pp, q, t = v * (1 - s), v * (1 - s * f), v * (1 - s * (1 - f))
+    sel = [(hi == 0) | (hi == 6), hi == 1, hi == 2, hi == 3, hi == 4]
+    r = np.select(sel, [v, q, pp, pp, t], v)
+    g = np.select(sel, [t, v, v, q, pp], pp)
+    b = np.select(sel, [pp, pp, t, v, v], q)
+    return np.stack([np.rint(f32(255) * c) for c in (r, g, b)], -1).astype(np.uint8)

@@ -108,26 +108,6 @@ def test_fp16_cavity_within_1e2_of_fp32(T):
     assert onp.rel_linf(u, ur) <= 1e-2
 
 
-def hsv_frame(u, p, blocked):
-    """numpy float32 restatement of lb_cuda_kernel.cu:27-67,308-319 on numpy-path moments."""
-    f32 = np.float32
-    PI = f32(3.141592653589)
-    u0, u1 = u[..., 0], u[..., 1]
-    h = (np.arctan2(u1, u0).astype(f32) + PI).astype(f32)
-    s = np.clip(f32(1000) * np.sqrt(u0 * u0 + u1 * u1), 0, 1).astype(f32)
-    v = np.clip(p, 0, 1).astype(f32)
-    h, s, v = (np.where(blocked, f32(0), a) for a in (h, s, v))
-    f = (h / (PI / f32(3))).astype(f32)
-    hi = np.floor(f)
-    f = f - hi
-    pp, q, t = v * (1 - s), v * (1 - s * f), v * (1 - s * (1 - f))
-    sel = [(hi == 0) | (hi == 6), hi == 1, hi == 2, hi == 3, hi == 4]
-    r = np.select(sel, [v, q, pp, pp, t], v)
-    g = np.select(sel, [t, v, v, q, pp], pp)
-    b = np.select(sel, [pp, pp, t, v, v], q)
-    return np.stack([np.rint(f32(255) * c) for c in (r, g, b)], -1).astype(np.uint8)
-
-
 def test_render_matches_the_reference_colour_map():
     from latticeboltzmann_amd.lb_hip_kernel import Solver
     N, M = 100, 200
@@ -147,7 +127,7 @@ def test_render_matches_the_reference_colour_map():
     u, p = s.read_moments()
     s.close()
     assert np.array_equal(frame, again)
-    want = hsv_frame(u, p, blocked)
+    want = onp.cuda_kernel_frame(u, p, blocked)  # oracle/: restates lb_cuda_kernel.cu:27-67,308-319
     diff = np.abs(frame.astype(int) - want.astype(int))
     assert (frame[blocked] == 0).all()
     assert diff.max() <= 1, f"max channel difference {diff.max()}"

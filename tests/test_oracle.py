@@ -223,3 +223,27 @@ def test_fp32_oracle_is_close_to_an_fp64_run():
     p64 = c.sum(axis=2)
     u64 = c @ e / p64[..., None]
     assert onp.rel_linf(p32, p64) < 1e-4 and onp.rel_linf(u32, u64) < 1e-4
+
+
+def test_cuda_kernel_frame_colour_map():
+    """oracle.cuda_kernel_frame (lb_cuda_kernel.cu:27-67,308-319; parity-unpinned) against an
+    independent HSV -> RGB (matplotlib's, the one the reference's numpy display uses,
+    latticeboltzmann.py:105) and on hand-checkable pixels."""
+    matplotlib = pytest.importorskip("matplotlib")
+    import matplotlib.colors
+    rng = np.random.default_rng(4)
+    N, M = 24, 40
+    u = (rng.random((N, M, 2), dtype=np.float32) - 0.5) * np.float32(0.003)
+    p = rng.random((N, M), dtype=np.float32) * np.float32(1.2)
+    blocked = rng.random((N, M)) < 0.1
+    f = onp.cuda_kernel_frame(u, p, blocked)
+    assert f.dtype == np.uint8 and f.shape == (N, M, 3) and (f[blocked] == 0).all()
+    h = (np.arctan2(u[..., 1], u[..., 0]).astype(np.float64) + np.pi) / (2 * np.pi)
+    s = np.clip(1000 * np.hypot(u[..., 0], u[..., 1]).astype(np.float64), 0, 1)
+    v = np.clip(p.astype(np.float64), 0, 1)
+    want = np.rint(255 * matplotlib.colors.hsv_to_rgb(np.stack([np.clip(h, 0, 1), s, v], -1)))
+    want[blocked] = 0
+    assert np.abs(f.astype(int) - want.astype(int)).max() <= 1
+    # zero velocity: atan2(0, 0) + pi = pi -> hue pi, saturation 0 -> grey of the density
+    g = onp.cuda_kernel_frame(np.zeros((1, 2, 2), np.float32), np.float32([[0.5, 2.0]]), np.zeros((1, 2), bool))
+    assert g[0, 0].tolist() == [128, 128, 128] and g[0, 1].tolist() == [255, 255, 255]
