@@ -222,6 +222,82 @@ __global__ __launch_bounds__(256) void kvar(const float* __restrict__ gin, float
     do_tile<FLAGS>(gin, gout, mask, geo, y, xb, lane);
 }
 
+// Marching variant: a wave owns one 64-column block and marches down R rows.  Every row is loaded
+// ONCE, whole (nine aligned planes of one 2304-byte block = the "same row" copy shape), shifted in
+// x by DPP with one scalar edge dword per shifted plane, and kept in a register history until the
+// three destination rows that pull from it have been computed.  P rows are in flight.
+template <int R, int P>
+__global__ __launch_bounds__(256) void kmarch(const float* __restrict__ gin, float* __restrict__ gout,
+                                              const uint64_t* __restrict__ mask, Geom geo) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int wpr = geo.Mb / 4;                 // workgroups per row of blocks
+    const int xb = (int)(wg % wpr) * 4 + wave;
+    const int y0 = (int)(wg / wpr) * R;
+    const int xbm = xb + 1 == geo.Mb ? 0 : xb + 1, xbp = xb == 0 ? geo.Mb - 1 : xb - 1;
+    const Omega om = omega_of(geo);
+    auto rowp = [&](int y) { y = y < 0 ? y + geo.N : (y >= geo.N ? y - geo.N : y); return gin + (long long)y * geo.rowStride; };
+    // one row: 9 aligned values + 6 edge values (uniform addresses -> scalar loads)
+    auto load = [&](int y, float* L, float* E) {
+        const float* r = rowp(y);
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            const int dx = dx_of(k), sl = slot_of(k) * LANES;
+            L[k] = __builtin_nontemporal_load(r + xb * CHUNK + lane + sl);
+            if (dx == 1) E[k] = r[xbp * CHUNK + 63 + sl];
+            else if (dx == -1) E[k] = r[xbm * CHUNK + sl];
+            else E[k] = 0.0f;
+        }
+    };
+    auto shift = [&](float* L, const float* E) {
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            const int dx = dx_of(k);
+            if (dx == 1) L[k] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(E[k]), __float_as_int(L[k]), 0x138, 0xf, 0xf, false));
+            else if (dx == -1) L[k] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(E[k]), __float_as_int(L[k]), 0x130, 0xf, 0xf, false));
+        }
+    };
+    float pre[P][Q], pree[P][Q];
+    float hm1[Q], h0[Q];  // shifted rows y-1 and y
+    {
+        float e[Q];
+        load(y0 - 1, hm1, e); shift(hm1, e);
+        load(y0, h0, e); shift(h0, e);
+    }
+#pragma unroll
+    for (int d = 0; d < P; d++) load(y0 + 1 + d, pre[d], pree[d]);
+#pragma unroll 1
+    for (int i = 0; i < R; i += P) {
+#pragma unroll
+        for (int d = 0; d < P; d++) {
+            const int y = y0 + i + d;
+            float hp1[Q];
+#pragma unroll
+            for (int k = 0; k < Q; k++) hp1[k] = pre[d][k];
+            float e[Q];
+#pragma unroll
+            for (int k = 0; k < Q; k++) e[k] = pree[d][k];
+            if (i + d + P < R + 0) load(y + 1 + P, pre[d], pree[d]);
+            shift(hp1, e);
+            float a[Q];
+#pragma unroll
+            for (int k = 0; k < Q; k++) {
+                const int dy = dy_of(k);
+                a[k] = dy == -1 ? hp1[k] : (dy == 0 ? h0[k] : hm1[k]);
+            }
+            const bool blocked = (mask[(long long)y * geo.Mb + xb] >> lane) & 1ull;
+            reflect(a, blocked);
+            collide(a, blocked, om);
+            float* o = gout + (long long)y * geo.rowStride + (long long)xb * CHUNK + lane;
+#pragma unroll
+            for (int k = 0; k < Q; k++) __builtin_nontemporal_store(a[k], o + slot_of(k) * LANES);
+#pragma unroll
+            for (int k = 0; k < Q; k++) { hm1[k] = h0[k]; h0[k] = hp1[k]; }
+        }
+    }
+}
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 // pure streaming copies of the same 9.66 GB buffer: what the memory system gives a kernel that does
 // nothing else (the yardstick for the fused kernel's 72 B/update)
@@ -448,6 +524,40 @@ int main(int argc, char** argv) {
             std::sort(t.begin(), t.end());
             printf("copy float4 nt-load nt-store dynLDS %6d B: %.3f ms  %.3f TB/s\n", ldsz[li], t[t.size() / 2], 2.0 * n * 4 / t[t.size() / 2] / 1e9);
         }
+    }
+    {   // marching kernels: check against base, then time under residency caps
+        float* ref; unsigned long long* cnt;
+        CHECK(hipMalloc(&ref, bytes)); CHECK(hipMalloc(&cnt, 8));
+        hipLaunchKernelGGL(vars[0].fn, dim3((unsigned)(ntiles / 4)), dim3(256), 0, 0, (const float*)a, ref, (const uint64_t*)mask, geo);
+        struct MV { const char* name; void (*fn)(const float*, float*, const uint64_t*, Geom); int R; };
+        // (deeper prefetch, P = 2 / 4, and R = 32 / 128 were timed too: 4.7-5.1 TB/s, no better)
+        const MV mv[] = {{"march R=64 P=1", kmarch<64, 1>, 64}};
+        const long long n = (long long)N * geo.rowStride;
+        for (const MV& m : mv) {
+            const unsigned grid = (unsigned)((long long)(geo.Mb / 4) * (N / m.R));
+            CHECK(hipMemset(cnt, 0, 8));
+            hipLaunchKernelGGL(m.fn, dim3(grid), dim3(256), 0, 0, (const float*)a, b, (const uint64_t*)mask, geo);
+            hipLaunchKernelGGL(diffk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const unsigned*)ref, (const unsigned*)b, n, cnt);
+            unsigned long long h = 0; CHECK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost));
+            if (h) printf("VARIANT %s DIFFERS from base in %llu values\n", m.name, h);
+            const int ldsz[] = {0, 20 << 10, 26 << 10, 36 << 10, 53 << 10, 80 << 10};
+            for (size_t li = 0; li < sizeof ldsz / sizeof ldsz[0]; li++) {
+                std::vector<float> t;
+                for (int r = 0; r < rounds + 1; r++) {
+                    CHECK(hipEventRecord(e0, 0));
+                    for (int i = 0; i < reps; i++) {
+                        hipLaunchKernelGGL(m.fn, dim3(grid), dim3(256), ldsz[li], 0, (const float*)a, b, (const uint64_t*)mask, geo);
+                        std::swap(a, b);
+                    }
+                    CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+                    float ms1; CHECK(hipEventElapsedTime(&ms1, e0, e1));
+                    if (r > 0) t.push_back(ms1 / reps);
+                }
+                std::sort(t.begin(), t.end());
+                printf("%-16s dynLDS %6d B: %.3f ms  %.3f TB/s\n", m.name, ldsz[li], t[t.size() / 2], (double)N * M * 72 / t[t.size() / 2] / 1e9);
+            }
+        }
+        CHECK(hipFree(ref)); CHECK(hipFree(cnt));
     }
     float chk[4]; CHECK(hipMemcpy(chk, a + 12345 * 64, sizeof chk, hipMemcpyDeviceToHost));
     printf("check %g %g %g %g\n", chk[0], chk[1], chk[2], chk[3]);
