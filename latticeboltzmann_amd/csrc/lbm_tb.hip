@@ -136,8 +136,9 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     const int s = wave / WPS + 1;
     const int j = wave % WPS;
     const int cx = 1 + j * (64 * CPL) + lane;  // ring-row index of cell 0; cell c is 64*c further
-    int off0[CPL], offm[CPL], offp[CPL], mblk[CPL];
-    unsigned mbit[CPL];
+    int off0[CPL];
+    unsigned bo0[CPL], bom[CPL], bop[CPL];  // byte offsets of the own / dx = -1 / dx = +1 source column in a row
+    unsigned mwoff[CPL], mbitmask[CPL];     // this cell's 32-bit mask word (byte offset in a mask row) and bit
     bool stored[CPL], ob_m[CPL], ob_p[CPL], last_col[CPL], care[CPL];
     bool any_xedge = false;
 #pragma unroll
@@ -160,10 +161,11 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         if (XMODE == XMODE_PERIODIC) { xm1 = xm1 >= M ? 0 : xm1; xp1 = xp1 < 0 ? M - 1 : xp1; }
         else { xm1 = xm1 >= M ? xn : xm1; xp1 = xp1 < 0 ? xn : xp1; }
         off0[c] = (xn >> 6) * CHUNK + (xn & 63);
-        offm[c] = (xm1 >> 6) * CHUNK + (xm1 & 63);
-        offp[c] = (xp1 >> 6) * CHUNK + (xp1 & 63);
-        mblk[c] = xn >> 6;
-        mbit[c] = xn & 63;
+        bo0[c] = (unsigned)off0[c] * (unsigned)sizeof(ST);
+        bom[c] = (unsigned)((xm1 >> 6) * CHUNK + (xm1 & 63)) * (unsigned)sizeof(ST);
+        bop[c] = (unsigned)((xp1 >> 6) * CHUNK + (xp1 & 63)) * (unsigned)sizeof(ST);
+        mwoff[c] = (unsigned)(xn >> 5) * 4u;
+        mbitmask[c] = 1u << (xn & 31);
     }
     const bool wave_xedge = __any(any_xedge);
 
@@ -190,22 +192,28 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     // and the mask words.  Pure loads from always-valid addresses (a source outside the domain is
     // replaced by the own cell); the inlet rule is applied when the row is consumed (inlet_fix),
     // so that no load sits behind a branch and the vmcnt bookkeeping stays exact.
-    auto load_row = [&](auto xedge, int r, V* dst, uint64_t* mw) {
+    // Addressing: the three row bases are wave-uniform (SGPR pairs) and a lane carries 32-bit byte
+    // offsets, so every load is `global_load_dword v, voffset, s[base] offset:slot` without any
+    // per-row address arithmetic on the vector unit (as in pull(), lbm_device.h).
+    auto load_row = [&](auto xedge, int r, V* dst, uint32_t* mw) {
         r = clampr(r);
         const int rn = wrap_row(r);
         const bool ob_u = r - 1 < qlo, ob_d = XMODE != XMODE_PERIODIC && r + 1 >= qhi;
         const int rnu = ob_u ? rn : wrap_row(r - 1), rnd = ob_d ? rn : wrap_row(r + 1);
-        const ST* p0 = gin + (long long)(rn + G) * RS;
-        const ST* pu = gin + (long long)(rnu + G) * RS;
-        const ST* pd = gin + (long long)(rnd + G) * RS;
+        const char* p0 = reinterpret_cast<const char*>(gin + (long long)(rn + G) * RS);
+        const char* pu = reinterpret_cast<const char*>(gin + (long long)(rnu + G) * RS);
+        const char* pd = reinterpret_cast<const char*>(gin + (long long)(rnd + G) * RS);
         // column offsets as plain values (never select between array elements behind a branch:
         // that turns the arrays into scratch memory).  Below the last domain row the dy = -1
         // source is the own cell: own row (pd = p0) AND own column.
-        int o0[CPL], om[CPL], op[CPL], omd[CPL], opd[CPL];
+        unsigned o0[CPL], om[CPL], op[CPL], omd[CPL], opd[CPL];
         bool xm[CPL], xp[CPL];
 #pragma unroll
         for (int c = 0; c < CPL; c++) {
-            const int a0 = off0[c], am = offm[c], ap = offp[c];
+            unsigned a0 = bo0[c], am = bom[c], ap = bop[c];
+            // keep the offsets 32-bit values of THIS iteration: hoisted out of the loop they would
+            // be zero-extended once and every load would pay a 64-bit vector add for its address
+            asm volatile("" : "+v"(a0), "+v"(am), "+v"(ap));
             o0[c] = a0; om[c] = am; op[c] = ap;
             omd[c] = ob_d ? a0 : am;
             opd[c] = ob_d ? a0 : ap;
@@ -213,27 +221,32 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         }
 #pragma unroll
         for (int k = 0; k < Q; k++) {
-            const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
-            const ST* rb = dy == 1 ? pu : (dy == 0 ? p0 : pd);
+            const int dy = dy_of(k), dx = dx_of(k);
+            const size_t sl = (size_t)slot_of(k) * LANES * sizeof(ST);
+            const char* rb = dy == 1 ? pu : (dy == 0 ? p0 : pd);
             float v[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
-                const int off = dx == 0 ? o0[c] : (dy == -1 ? (dx == 1 ? opd[c] : omd[c])
-                                                             : (dx == 1 ? op[c] : om[c]));
-                const ST* pp = rb + off;
+                const unsigned off = dx == 0 ? o0[c] : (dy == -1 ? (dx == 1 ? opd[c] : omd[c])
+                                                                  : (dx == 1 ? op[c] : om[c]));
+                const ST* pp = reinterpret_cast<const ST*>(rb + sl + (size_t)off);
                 if (decltype(xedge)::value && dx != 0) {
                     // a source column outside the domain: the own cell (any valid address does
                     // for dx = +1, which inlet_fix overwrites)
-                    const ST* own = p0 + o0[c];
+                    const ST* own = reinterpret_cast<const ST*>(p0 + sl + (size_t)o0[c]);
                     pp = (dx == 1 ? xp[c] : xm[c]) ? own : pp;
                 }
-                v[c] = LBM_TB_LOAD(pp + sl);
+                v[c] = LBM_TB_LOAD(pp);
             }
             dst[k] = L::make(v);
         }
-        const uint64_t* mrow = mask + (long long)(rn + G) * geo.Mb;
+        const char* mrow = reinterpret_cast<const char*>(mask + (long long)(rn + G) * geo.Mb);
 #pragma unroll
-        for (int c = 0; c < CPL; c++) mw[c] = mrow[mblk[c]];
+        for (int c = 0; c < CPL; c++) {
+            unsigned mo = mwoff[c];
+            asm volatile("" : "+v"(mo));
+            mw[c] = *reinterpret_cast<const uint32_t*>(mrow + (size_t)mo);
+        }
     };
     auto inlet_fix = [&](auto xedge, int r, V* a) {
         if (XMODE == XMODE_PERIODIC) return;  // no domain edge in x, and y wraps or is a seam
@@ -269,8 +282,6 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         constexpr int PH = decltype(ph)::value;
         // the previous stage wrote row r+1 one, row r two and row r-1 three iterations ago (below
         // the last domain row: the phantom row, which holds this row's own dy = -1 values)
-#pragma unroll
-        for (int c = 0; c < CPL; c++) blocked[c] = rd_flag[C::flag_off(PH, 2) + 64 * c] != 0;
         const bool ob_u = XMODE != XMODE_PERIODIC && r - 1 < qlo;
 #pragma unroll
         for (int k = 0; k < Q; k++) {
@@ -292,6 +303,10 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
             }
             a[k] = L::make(v);
         }
+        // the flags last: their first use (reflect's wave vote) would otherwise make hipcc wait
+        // for them before it has issued the population reads
+#pragma unroll
+        for (int c = 0; c < CPL; c++) blocked[c] = rd_flag[C::flag_off(PH, 2) + 64 * c] != 0;
         if (ob_u) {  // top inlet, wave-uniform and rare (see inlet_fix)
 #pragma unroll
             for (int k = 0; k < Q; k++) {
@@ -359,16 +374,16 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
             // PF rows in flight: row q+PF is requested while row q is consumed; the mask words
             // travel with their row (vmcnt retires in order)
             V pre[PF][Q];
-            uint64_t pmw[PF][CPL];
+            uint32_t pmw[PF][CPL];
 #pragma unroll
             for (int d = 0; d < PF; d++) load_row(xedge, q + d, pre[d], pmw[d]);
-            auto it = [&](auto ph, V* pr, uint64_t* mw) {
+            auto it = [&](auto ph, V* pr, uint32_t* mw) {
                 V a[Q];
                 bool blocked[CPL];
 #pragma unroll
                 for (int k = 0; k < Q; k++) a[k] = pr[k];
 #pragma unroll
-                for (int c = 0; c < CPL; c++) blocked[c] = (mw[c] >> mbit[c]) & 1ull;
+                for (int c = 0; c < CPL; c++) blocked[c] = (mw[c] & mbitmask[c]) != 0;
                 load_row(xedge, q + PF, pr, mw);
                 // rows outside this stage's range (pipeline fill and drain: 3(T-1) of the
                 // iterations) are nobody's input: skip their arithmetic, keep loads and barrier
