@@ -84,8 +84,9 @@ __device__ __forceinline__ bool relax_is_identity(const float a[Q], float p, flo
     for (int k = 1; k < Q; k++) sg |= __float_as_uint(a[k]);
     // a blocked cell does not veto its wave: its relaxation factor is 1 and the caller computes
     // (a - eq) + eq for it (exact in either product: v * 1 = v)
-    const bool ok = !care || blocked || ((int)sg >= 0 && p >= 7.888609052210118e-31f /* 2^-100 */ &&
-                    p <= 1.2676506002282294e30f /* 2^100 */ && c <= 0.125f);
+    // (bitwise, not short-circuit: see relax_is_identity2)
+    const bool ok = !care | blocked | (((int)sg >= 0) & (p >= 7.888609052210118e-31f /* 2^-100 */) &
+                    (p <= 1.2676506002282294e30f /* 2^100 */) & (c <= 0.125f));
     return __all(ok);
 }
 // `cells *= omega` (latticeboltzmann.py:112).  The reference's omega is a FLOAT64 array
@@ -391,46 +392,64 @@ __device__ __forceinline__ bool relax_is_identity2(const f2 a[Q], f2 p, f2 c, bo
 #pragma unroll
     for (int k = 1; k < Q; k++) { sx |= __float_as_uint(a[k].x); sy |= __float_as_uint(a[k].y); }
     const float lo = 7.888609052210118e-31f, hi = 1.2676506002282294e30f;
-    const bool ok0 = !care0 || b0 || ((int)sx >= 0 && p.x >= lo && p.x <= hi && c.x <= 0.125f);
-    const bool ok1 = !care1 || b1 || ((int)sy >= 0 && p.y >= lo && p.y <= hi && c.y <= 0.125f);
-    return __all(ok0 && ok1);
+    // bitwise, not short-circuit: a lane-divergent branch here would make hipcc structurize the
+    // whole collide (flow blocks, register copies on the common path)
+    const bool ok0 = !care0 | b0 | (((int)sx >= 0) & (p.x >= lo) & (p.x <= hi) & (c.x <= 0.125f));
+    const bool ok1 = !care1 | b1 | (((int)sy >= 0) & (p.y >= lo) & (p.y <= hi) & (c.y <= 0.125f));
+    return __all(ok0 & ok1);
 }
 
-__device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, const Omega& om,
-                                         bool care0 = true, bool care1 = true) {
+// The result is handed to `sink(const f2 out[Q])` instead of being returned: the common case (tiny
+// omega, ordinary cells, no obstacle in the wave) passes eq[] on as it is, every other case
+// corrects eq[] inside ONE rare, wave-uniform branch and calls the sink from there.  Returned
+// through a[] the two paths would join in a phi, and hipcc places that phi's nine register-pair
+// copies on the common path (18 of ~150 vector instructions per row of the LDS kernel).
+template <class Sink>
+__device__ __forceinline__ void collide2_to(const f2 a[Q], bool b0, bool b1, const Omega& om,
+                                            bool care0, bool care1, Sink sink) {
     f2 p, u0, u1, eq[Q];
     moments2(a, p, u0, u1);
     const f2 c = equilibrium2(u0, u1, p, eq);
-    if (om.tiny && relax_is_identity2(a, p, c, b0, b1, care0, care1)) {  // wave-uniform
-        if (__any(b0 || b1)) {  // obstacles are sparse: most waves skip this
+    // both votes evaluated unconditionally and joined bitwise: one wave-uniform branch
+    const bool fast = om.tiny & relax_is_identity2(a, p, c, b0, b1, care0, care1);
+    const bool obstacle = __any(b0 | b1);
+    if (__builtin_expect(!fast | obstacle, 0)) {
+        if (fast) {  // only blocked cells relax (omega = 1: exact in either product)
 #pragma unroll
             for (int k = 0; k < Q; k++) {
-                const f2 v = (a[k] - eq[k]) + eq[k];  // blocked cells: omega = 1
-                a[k] = f2{b0 ? v.x : eq[k].x, b1 ? v.y : eq[k].y};
+                const f2 v = (a[k] - eq[k]) + eq[k];
+                eq[k] = f2{b0 ? v.x : eq[k].x, b1 ? v.y : eq[k].y};
             }
-        } else {
+        } else if (om.f32_exact) {  // wave-uniform
+            const f2 o = f2{b0 ? 1.0f : om.f, b1 ? 1.0f : om.f};
 #pragma unroll
-            for (int k = 0; k < Q; k++) a[k] = eq[k];
+            for (int k = 0; k < Q; k++) {
+                f2 v = a[k] - eq[k];
+                v = v * o;
+                eq[k] = v + eq[k];
+            }
+        } else {  // the reference's float64 omega: double product, one rounding (no packed f64 exists)
+            const double o0 = b0 ? 1.0 : om.d, o1 = b1 ? 1.0 : om.d;
+#pragma unroll
+            for (int k = 0; k < Q; k++) {
+                f2 v = a[k] - eq[k];
+                v = f2{(float)((double)v.x * o0), (float)((double)v.y * o1)};
+                eq[k] = v + eq[k];
+            }
         }
-        return;
+        asm volatile("; collide2_to: general path");  // keeps the two sink copies from being merged again
+        sink(eq);
+    } else {
+        asm volatile("; collide2_to: common path");
+        sink(eq);
     }
-    if (om.f32_exact) {  // wave-uniform
-        const f2 o = f2{b0 ? 1.0f : om.f, b1 ? 1.0f : om.f};
+}
+__device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, const Omega& om,
+                                         bool care0 = true, bool care1 = true) {
+    collide2_to(a, b0, b1, om, care0, care1, [&](const f2* out) {
 #pragma unroll
-        for (int k = 0; k < Q; k++) {
-            f2 v = a[k] - eq[k];
-            v = v * o;
-            a[k] = v + eq[k];
-        }
-    } else {  // the reference's float64 omega: double product, one rounding (no packed f64 exists)
-        const double o0 = b0 ? 1.0 : om.d, o1 = b1 ? 1.0 : om.d;
-#pragma unroll
-        for (int k = 0; k < Q; k++) {
-            f2 v = a[k] - eq[k];
-            v = f2{(float)((double)v.x * o0), (float)((double)v.y * o1)};
-            a[k] = v + eq[k];
-        }
-    }
+        for (int k = 0; k < Q; k++) a[k] = out[k];
+    });
 }
 
 // --- kernel-semantics compatibility mode (XMODE_CUDA) -----------------------------

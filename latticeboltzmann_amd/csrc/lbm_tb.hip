@@ -390,8 +390,8 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
                 if (live(q)) {
                     inlet_fix(xedge, clampr(q), a);
                     reflect_v(a, blocked);
-                    collide_v(a, blocked, omega, care);
-                    to_lds(xedge, ph, q, a, blocked);
+                    collide_to(a, blocked, omega, care,
+                               [&](const V* out) { to_lds(xedge, ph, q, out, blocked); });
                 }
                 q += 1;
                 __syncthreads();
@@ -410,18 +410,21 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
                     bool blocked[CPL];
                     gather(xedge, ph, q, a, blocked);
                     reflect_v(a, blocked);
-                    collide_v(a, blocked, omega, care);
-                    if (s < T) {
-                        to_lds(xedge, ph, q, a, blocked);
-                    } else {
+                    collide_to(a, blocked, omega, care, [&](const V* out) {
+                        if (s < T) {
+                            to_lds(xedge, ph, q, out, blocked);
+                        } else {
 #pragma unroll
-                        for (int c = 0; c < CPL; c++) {
-                            if (stored[c]) {
+                            for (int c = 0; c < CPL; c++) {
+                                if (stored[c]) {
 #pragma unroll
-                                for (int k = 0; k < Q; k++)
-                                    LBM_TB_STORE(orow + off0[c] + slot_of(k) * LANES, L::get(a[k], c));
+                                    for (int k = 0; k < Q; k++)
+                                        LBM_TB_STORE(orow + off0[c] + slot_of(k) * LANES, L::get(out[k], c));
+                                }
                             }
                         }
+                    });
+                    if (s == T) {
                         // next row of the output; a wrapped domain restarts at row 0
                         orow += RS;
                         if (wrapy && wrap_row(q) == N - 1) orow = gout + (long long)G * RS;

@@ -61,6 +61,16 @@ __device__ __forceinline__ void reflect_v(float* a, const bool* b) { reflect(a, 
 __device__ __forceinline__ void reflect_v(f2* a, const bool* b) { reflect2(a, b[0], b[1]); }
 __device__ __forceinline__ void collide_v(float* a, const bool* b, const Omega& om, const bool* care) { collide(a, b[0], om, care[0]); }
 __device__ __forceinline__ void collide_v(f2* a, const bool* b, const Omega& om, const bool* care) { collide2(a, b[0], b[1], om, care[0], care[1]); }
+// collide and hand the result to sink(const V*): see collide2_to (lbm_device.h)
+template <class Sink>
+__device__ __forceinline__ void collide_to(float* a, const bool* b, const Omega& om, const bool* care, Sink sink) {
+    collide(a, b[0], om, care[0]);
+    sink(a);
+}
+template <class Sink>
+__device__ __forceinline__ void collide_to(f2* a, const bool* b, const Omega& om, const bool* care, Sink sink) {
+    collide2_to(a, b[0], b[1], om, care[0], care[1], sink);
+}
 
 
 }  // namespace lbm
