@@ -56,6 +56,13 @@ struct Omega {
 __device__ __forceinline__ Omega omega_of(const Geom& geo) {
     return Omega{geo.omega, geo.omega_f, geo.omega_f32_exact != 0, geo.omega_tiny != 0};
 }
+// Wave votes on the lane mask itself (compare -> SGPR pair -> s_cmp): HIP's __any / __all go
+// through an integer per lane (v_cndmask + v_cmp) first.
+typedef unsigned long long lanemask;
+__device__ __forceinline__ lanemask ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
+
 constexpr double OMEGA_TINY_MAX = 1.0 / 17179869184.0;  // 2^-34 = 5.8e-11 (the reference's OMEGA is 1e-14)
 
 // For |omega| <= 2^-34 -- the reference's own setting, OMEGA = 1e-14 (latticeboltzmann.py:80), is
@@ -87,7 +94,7 @@ __device__ __forceinline__ bool relax_is_identity(const float a[Q], float p, flo
     // (bitwise, not short-circuit: see relax_is_identity2)
     const bool ok = !care | blocked | (((int)sg >= 0) & (p >= 7.888609052210118e-31f /* 2^-100 */) &
                     (p <= 1.2676506002282294e30f /* 2^100 */) & (c <= 0.125f));
-    return __all(ok);
+    return wave_all(ok);
 }
 // `cells *= omega` (latticeboltzmann.py:112).  The reference's omega is a FLOAT64 array
 // (np.where(blocked, np.array(1), np.array(OMEGA)), :98), so numpy multiplies the float32 cell by
@@ -207,7 +214,7 @@ __device__ __forceinline__ void pull(const T* __restrict__ g, const Geom& geo, i
 // Obstacles are sparse (< 1 % of the reference's scenes): a wave without a blocked lane skips
 // the eight selects.
 __device__ __forceinline__ void reflect(float t[Q], bool blocked) {
-    if (__any(blocked)) {
+    if (wave_any(blocked)) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             float a = t[k], b = t[8 - k];
@@ -236,7 +243,7 @@ __device__ __forceinline__ void moments(const float a[Q], float& p, float& u0, f
     // np.nan_to_num only acts on non-finite values (p == 0 or a blown-up cell): rare, so the
     // fix-up is a wave-uniform branch instead of ten selects per cell.
     const float inf = __builtin_inff();
-    if (__any(!(__builtin_fabsf(u0) < inf) || !(__builtin_fabsf(u1) < inf))) {
+    if (wave_any(!(__builtin_fabsf(u0) < inf) || !(__builtin_fabsf(u1) < inf))) {
         u0 = nan_to_num(u0);
         u1 = nan_to_num(u1);
     }
@@ -273,7 +280,7 @@ __device__ __forceinline__ void collide(float a[Q], bool blocked, const Omega& o
     moments(a, p, u0, u1);
     const float c = equilibrium(u0, u1, p, eq);
     if (om.tiny && relax_is_identity(a, p, c, blocked, care)) {  // wave-uniform
-        if (__any(blocked)) {  // obstacles are sparse: most waves skip this
+        if (wave_any(blocked)) {  // obstacles are sparse: most waves skip this
 #pragma unroll
             for (int k = 0; k < Q; k++) {
                 const float v = a[k] - eq[k];
@@ -311,8 +318,10 @@ __device__ __forceinline__ void collide(float a[Q], bool blocked, const Omega& o
 // IEEE operations in the same order as the scalar functions above: bit-identical results.
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void reflect2(f2 t[Q], bool b0, bool b1) {
-    if (__any(b0 || b1)) {
+// bm0 / bm1: ballot(b0) / ballot(b1), taken by the caller right where b0 / b1 are computed (a
+// ballot of a bool that was defined in another basic block costs a v_cndmask + v_cmp round trip)
+__device__ __forceinline__ void reflect2(f2 t[Q], bool b0, bool b1, lanemask bm0, lanemask bm1) {
+    if ((bm0 | bm1) != 0) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const f2 a = t[k], b = t[8 - k];
@@ -321,6 +330,7 @@ __device__ __forceinline__ void reflect2(f2 t[Q], bool b0, bool b1) {
         }
     }
 }
+__device__ __forceinline__ void reflect2(f2 t[Q], bool b0, bool b1) { reflect2(t, b0, b1, ballot(b0), ballot(b1)); }
 
 __device__ __forceinline__ void moments2(const f2 a[Q], f2& p, f2& u0, f2& u1) {
     p = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + a[8];
@@ -360,7 +370,7 @@ __device__ __forceinline__ void moments2(const f2 a[Q], f2& p, f2& u0, f2& u1) {
     const bool odd = emin < -80 || emax > 40 ||
                      !(__builtin_fabsf(u0.x) < big) || !(__builtin_fabsf(u0.y) < big) ||
                      !(__builtin_fabsf(u1.x) < big) || !(__builtin_fabsf(u1.y) < big);
-    if (__any(odd)) {
+    if (wave_any(odd)) {
         u0 = m0 / p;  // IEEE divisions
         u1 = m1 / p;
         u0 = f2{nan_to_num(u0.x), nan_to_num(u0.y)};
@@ -385,18 +395,21 @@ __device__ __forceinline__ f2 equilibrium2(f2 u0, f2 u1, f2 p, f2 eq[Q]) {
     return c;
 }
 
-// relax_is_identity() for the two cells of a lane
-__device__ __forceinline__ bool relax_is_identity2(const f2 a[Q], f2 p, f2 c, bool b0, bool b1,
-                                                   bool care0, bool care1) {
+// relax_is_identity() for the two cells of a lane.  bm = ballot(blocked), cm = ballot(care), per cell.
+// Combined on the lane masks (one SGPR pair per compare, scalar and / or): no lane-divergent
+// branch (short-circuit evaluation would make hipcc structurize the whole collide: flow blocks,
+// register copies on the common path) and no per-lane integer for the vote.
+__device__ __forceinline__ bool relax_is_identity2(const f2 a[Q], f2 p, f2 c, lanemask bm0, lanemask bm1,
+                                                   lanemask cm0, lanemask cm1) {
     unsigned sx = __float_as_uint(a[0].x), sy = __float_as_uint(a[0].y);
 #pragma unroll
     for (int k = 1; k < Q; k++) { sx |= __float_as_uint(a[k].x); sy |= __float_as_uint(a[k].y); }
     const float lo = 7.888609052210118e-31f, hi = 1.2676506002282294e30f;
-    // bitwise, not short-circuit: a lane-divergent branch here would make hipcc structurize the
-    // whole collide (flow blocks, register copies on the common path)
-    const bool ok0 = !care0 | b0 | (((int)sx >= 0) & (p.x >= lo) & (p.x <= hi) & (c.x <= 0.125f));
-    const bool ok1 = !care1 | b1 | (((int)sy >= 0) & (p.y >= lo) & (p.y <= hi) & (c.y <= 0.125f));
-    return __all(ok0 & ok1);
+    const lanemask good0 = ballot((int)sx >= 0) & ballot(p.x >= lo) & ballot(p.x <= hi) & ballot(c.x <= 0.125f);
+    const lanemask good1 = ballot((int)sy >= 0) & ballot(p.y >= lo) & ballot(p.y <= hi) & ballot(c.y <= 0.125f);
+    const lanemask ok0 = ~cm0 | bm0 | good0;
+    const lanemask ok1 = ~cm1 | bm1 | good1;
+    return (~(ok0 & ok1) & ballot(true)) == 0;
 }
 
 // The result is handed to `sink(const f2 out[Q])` instead of being returned: the common case (tiny
@@ -405,14 +418,14 @@ __device__ __forceinline__ bool relax_is_identity2(const f2 a[Q], f2 p, f2 c, bo
 // through a[] the two paths would join in a phi, and hipcc places that phi's nine register-pair
 // copies on the common path (18 of ~150 vector instructions per row of the LDS kernel).
 template <class Sink>
-__device__ __forceinline__ void collide2_to(const f2 a[Q], bool b0, bool b1, const Omega& om,
-                                            bool care0, bool care1, Sink sink) {
+__device__ __forceinline__ void collide2_to(const f2 a[Q], bool b0, bool b1, lanemask bm0, lanemask bm1,
+                                            const Omega& om, lanemask cm0, lanemask cm1, Sink sink) {
     f2 p, u0, u1, eq[Q];
     moments2(a, p, u0, u1);
     const f2 c = equilibrium2(u0, u1, p, eq);
     // both votes evaluated unconditionally and joined bitwise: one wave-uniform branch
-    const bool fast = om.tiny & relax_is_identity2(a, p, c, b0, b1, care0, care1);
-    const bool obstacle = __any(b0 | b1);
+    const bool fast = om.tiny & relax_is_identity2(a, p, c, bm0, bm1, cm0, cm1);
+    const bool obstacle = (bm0 | bm1) != 0;
     if (__builtin_expect(!fast | obstacle, 0)) {
         if (fast) {  // only blocked cells relax (omega = 1: exact in either product)
 #pragma unroll
@@ -446,7 +459,7 @@ __device__ __forceinline__ void collide2_to(const f2 a[Q], bool b0, bool b1, con
 }
 __device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, const Omega& om,
                                          bool care0 = true, bool care1 = true) {
-    collide2_to(a, b0, b1, om, care0, care1, [&](const f2* out) {
+    collide2_to(a, b0, b1, ballot(b0), ballot(b1), om, ballot(care0), ballot(care1), [&](const f2* out) {
 #pragma unroll
         for (int k = 0; k < Q; k++) a[k] = out[k];
     });

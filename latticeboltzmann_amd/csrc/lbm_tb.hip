@@ -138,8 +138,10 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     const int cx = 1 + j * (64 * CPL) + lane;  // ring-row index of cell 0; cell c is 64*c further
     int off0[CPL];
     unsigned bo0[CPL], bom[CPL], bop[CPL];  // byte offsets of the own / dx = -1 / dx = +1 source column in a row
-    unsigned mwoff[CPL], mbitmask[CPL];     // this cell's 32-bit mask word (byte offset in a mask row) and bit
+    unsigned mwoff[CPL];                    // this cell's 32-bit mask word (byte offset in a mask row)
     bool stored[CPL], ob_m[CPL], ob_p[CPL], last_col[CPL], care[CPL];
+    lanemask caremask[CPL];
+    unsigned mbit[CPL];  // this cell's bit in its 32-bit mask word
     bool any_xedge = false;
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
@@ -152,6 +154,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         // beyond compute on stale ring contents and nobody reads what they produce
         const int wc = j * (64 * CPL) + c * 64 + lane;
         care[c] = wc >= s - 1 && wc < C::W - (s - 1);
+        caremask[c] = ballot(care[c]);
         // x edge rule (reference mode only): source of dx = -1 / +1 outside the domain
         ob_m[c] = XMODE != XMODE_PERIODIC && x + 1 >= M;
         ob_p[c] = XMODE != XMODE_PERIODIC && x - 1 < 0;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         bom[c] = (unsigned)((xm1 >> 6) * CHUNK + (xm1 & 63)) * (unsigned)sizeof(ST);
         bop[c] = (unsigned)((xp1 >> 6) * CHUNK + (xp1 & 63)) * (unsigned)sizeof(ST);
         mwoff[c] = (unsigned)(xn >> 5) * 4u;
-        mbitmask[c] = 1u << (xn & 31);
+        mbit[c] = xn & 31;
     }
     const bool wave_xedge = __any(any_xedge);
 
@@ -278,7 +281,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     };
     // stages 2..T, iteration phase PH = i & 3: gather the pulled populations of row r and the
     // blocked flags from the ring of level s-1
-    auto gather = [&](auto xedge, auto ph, int r, V* a, bool* blocked) {
+    auto gather = [&](auto xedge, auto ph, int r, V* a, Flags<CPL>& blocked) {
         constexpr int PH = decltype(ph)::value;
         // the previous stage wrote row r+1 one, row r two and row r-1 three iterations ago (below
         // the last domain row: the phantom row, which holds this row's own dy = -1 values)
@@ -306,7 +309,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         // the flags last: their first use (reflect's wave vote) would otherwise make hipcc wait
         // for them before it has issued the population reads
 #pragma unroll
-        for (int c = 0; c < CPL; c++) blocked[c] = rd_flag[C::flag_off(PH, 2) + 64 * c] != 0;
+        for (int c = 0; c < CPL; c++) blocked.set(c, rd_flag[C::flag_off(PH, 2) + 64 * c]);
         if (ob_u) {  // top inlet, wave-uniform and rare (see inlet_fix)
 #pragma unroll
             for (int k = 0; k < Q; k++) {
@@ -327,7 +330,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         if (std::is_same<ST, __half>::value) return __half2float(__float2half_rn(v));
         return v;
     };
-    auto to_lds = [&](auto xedge, auto ph, int q, const V* a, const bool* blocked) {
+    auto to_lds = [&](auto xedge, auto ph, int q, const V* a, const Flags<CPL>& blocked) {
         constexpr int PH = decltype(ph)::value;
         if (XMODE != XMODE_PERIODIC && q == qhi) {
             // phantom row below the last domain row (wave-uniform, once per chunk at most): the
@@ -351,7 +354,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
                 *reinterpret_cast<float*>(wr_base + C::slot_off(slot_of(k), PH, 0) + 256 * c) = ring_value(L::get(a[k], c));
         }
 #pragma unroll
-        for (int c = 0; c < CPL; c++) wr_flag[C::flag_off(PH, 0) + 64 * c] = blocked[c];
+        for (int c = 0; c < CPL; c++) wr_flag[C::flag_off(PH, 0) + 64 * c] = (unsigned char)blocked.raw[c];
         if (decltype(xedge)::value) {
 #pragma unroll
             for (int k = 0; k < Q; k++) {
@@ -379,18 +382,18 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
             for (int d = 0; d < PF; d++) load_row(xedge, q + d, pre[d], pmw[d]);
             auto it = [&](auto ph, V* pr, uint32_t* mw) {
                 V a[Q];
-                bool blocked[CPL];
+                Flags<CPL> blocked;
 #pragma unroll
                 for (int k = 0; k < Q; k++) a[k] = pr[k];
 #pragma unroll
-                for (int c = 0; c < CPL; c++) blocked[c] = (mw[c] & mbitmask[c]) != 0;
+                for (int c = 0; c < CPL; c++) blocked.set(c, __builtin_amdgcn_ubfe(mw[c], mbit[c], 1u));
                 load_row(xedge, q + PF, pr, mw);
                 // rows outside this stage's range (pipeline fill and drain: 3(T-1) of the
                 // iterations) are nobody's input: skip their arithmetic, keep loads and barrier
                 if (live(q)) {
                     inlet_fix(xedge, clampr(q), a);
                     reflect_v(a, blocked);
-                    collide_to(a, blocked, omega, care,
+                    collide_to(a, blocked, omega, care, caremask,
                                [&](const V* out) { to_lds(xedge, ph, q, out, blocked); });
                 }
                 q += 1;
@@ -407,10 +410,10 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
             auto it = [&](auto ph) {
                 if (live(q)) {
                     V a[Q];
-                    bool blocked[CPL];
+                    Flags<CPL> blocked;
                     gather(xedge, ph, q, a, blocked);
                     reflect_v(a, blocked);
-                    collide_to(a, blocked, omega, care, [&](const V* out) {
+                    collide_to(a, blocked, omega, care, caremask, [&](const V* out) {
                         if (s < T) {
                             to_lds(xedge, ph, q, out, blocked);
                         } else {

@@ -57,19 +57,29 @@ template <> struct LaneV<2> {
     static __device__ __forceinline__ V make(const float* v) { return f2{v[0], v[1]}; }
     static __device__ __forceinline__ float get(V v, int c) { return c == 0 ? v.x : v.y; }
 };
+// blocked flags of a lane's cells: the byte that travels through the rings (0 / nonzero), the
+// lane predicate and its ballot (taken where the predicate is computed, see reflect2)
+template <int CPL> struct Flags {
+    unsigned raw[CPL];
+    bool b[CPL];
+    lanemask m[CPL];
+    __device__ __forceinline__ void set(int c, unsigned r) { raw[c] = r; b[c] = r != 0; m[c] = ballot(r != 0); }
+};
 __device__ __forceinline__ void reflect_v(float* a, const bool* b) { reflect(a, b[0]); }
 __device__ __forceinline__ void reflect_v(f2* a, const bool* b) { reflect2(a, b[0], b[1]); }
+__device__ __forceinline__ void reflect_v(float* a, const Flags<1>& f) { reflect(a, f.b[0]); }
+__device__ __forceinline__ void reflect_v(f2* a, const Flags<2>& f) { reflect2(a, f.b[0], f.b[1], f.m[0], f.m[1]); }
 __device__ __forceinline__ void collide_v(float* a, const bool* b, const Omega& om, const bool* care) { collide(a, b[0], om, care[0]); }
 __device__ __forceinline__ void collide_v(f2* a, const bool* b, const Omega& om, const bool* care) { collide2(a, b[0], b[1], om, care[0], care[1]); }
-// collide and hand the result to sink(const V*): see collide2_to (lbm_device.h)
+// collide and hand the result to sink(const V*): see collide2_to (lbm_device.h); cm = ballot(care)
 template <class Sink>
-__device__ __forceinline__ void collide_to(float* a, const bool* b, const Omega& om, const bool* care, Sink sink) {
-    collide(a, b[0], om, care[0]);
+__device__ __forceinline__ void collide_to(float* a, const Flags<1>& f, const Omega& om, const bool* care, const lanemask*, Sink sink) {
+    collide(a, f.b[0], om, care[0]);
     sink(a);
 }
 template <class Sink>
-__device__ __forceinline__ void collide_to(f2* a, const bool* b, const Omega& om, const bool* care, Sink sink) {
-    collide2_to(a, b[0], b[1], om, care[0], care[1], sink);
+__device__ __forceinline__ void collide_to(f2* a, const Flags<2>& f, const Omega& om, const bool*, const lanemask* cm, Sink sink) {
+    collide2_to(a, f.b[0], f.b[1], f.m[0], f.m[1], om, cm[0], cm[1], sink);
 }
 
 
