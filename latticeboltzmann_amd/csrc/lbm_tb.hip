@@ -135,7 +135,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     constexpr int WPS = NB / CPL;  // waves per stage
     const int s = wave / WPS + 1;
     const int j = wave % WPS;
-    const int cx = 1 + j * (64 * CPL) + lane;  // ring-row index of cell 0; cell c is 64*c further
+    const int cx = C::PADC + j * (64 * CPL) + lane;  // ring-row index of cell 0; cell c is 64*c further
     int off0[CPL];
     unsigned bo0[CPL], bom[CPL], bop[CPL];  // byte offsets of the own / dx = -1 / dx = +1 source column in a row
     unsigned mwoff[CPL];                    // this cell's 32-bit mask word (byte offset in a mask row)
@@ -184,12 +184,12 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     auto clampr = [&](int r) { return min(max(r, rlo), rhi - 1); };
 
     // LDS views (layout: struct TB).  Level l (1..T-1) lives at lds + (l-1)*LEVB.
-    unsigned char* const wr_base = lds + (s - 1) * C::LEVB + cx * 4;  // this stage's level (s < T)
-    const unsigned char* const rd_base = lds + (s - 2) * C::LEVB + cx * 4;  // level s-1 (s > 1)
-    unsigned char* const wr_flag = lds + (s - 1) * C::LEVB + cx;
-    const unsigned char* const rd_flag = lds + (s - 2) * C::LEVB + cx;
-    unsigned char* const wr_lev = lds + (s - 1) * C::LEVB;        // side ring of the last column
-    const unsigned char* const rd_lev = lds + (s - 2) * C::LEVB;
+    unsigned char* const wr_lev = lds + C::FRONT + (s - 1) * C::LEVB;  // this stage's level (s < T)
+    const unsigned char* const rd_lev = lds + C::FRONT + (s - 2) * C::LEVB;  // level s-1 (s > 1)
+    unsigned char* const wr_base = wr_lev + cx * 4;
+    const unsigned char* const rd_base = rd_lev + cx * 4;
+    unsigned char* const wr_flag = wr_lev + cx;
+    const unsigned char* const rd_flag = rd_lev + cx;
 
     // stage 1: issue the CPL x 9 pulled loads of logical row r (clamped into this stage's range)
     // and the mask words.  Pure loads from always-valid addresses (a source outside the domain is
@@ -448,11 +448,11 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     // next level read them (their results are nobody's input).  Give them an ordinary value once:
     // stale LDS there could hold anything, and one non-finite or zero-density lane sends its whole
     // wave down the exact-division path (and, for tiny omega, the general relaxation) in every row.
-    if (LBM_TB_PADINIT && s < T && j == 0 && lane < 2 * (C::DA * 3 + 4 * 6)) {
+    if (LBM_TB_PADINIT && C::PADC && s < T && j == 0 && lane < 2 * (C::DA * 3 + 4 * 6)) {
         const int n = lane >> 1, side = lane & 1;
         const int off = n < C::DA * 3 ? (n / 3) * C::A_ROW + (n % 3) * C::RW * 4
                                       : C::B_OFF + ((n - C::DA * 3) / 6) * C::B_ROW + ((n - C::DA * 3) % 6) * C::RW * 4;
-        *reinterpret_cast<float*>(lds + (s - 1) * C::LEVB + off + side * (C::RW - 1) * 4) = 1.0f;
+        *reinterpret_cast<float*>(wr_lev + off + side * (C::RW - 1) * 4) = 1.0f;
     }
     // A wave whose columns all lie beyond what the strip needs (the last strip of a row is
     // usually narrower than the window) only keeps the barriers company: no loads, no arithmetic.

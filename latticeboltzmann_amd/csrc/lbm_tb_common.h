@@ -3,6 +3,10 @@
 #pragma once
 #include <type_traits>
 
+#ifndef LBM_TB_PADC
+#define LBM_TB_PADC 0
+#endif
+
 #include "lbm_internal.h"
 
 namespace lbm {
@@ -27,14 +31,24 @@ struct TB {
     static constexpr int DA = 2;                 // ring depth of the dy = -1 slots
     static constexpr int W = NB * 64;            // window width (columns computed per stage)
     static constexpr int SW = W - 2 * MARG;      // strip width (columns stored)
-    static constexpr int RW = W + 2;             // floats per slot row (+1 pad either side)
+    // A slot row holds exactly the W window columns (a multiple of 64 floats = 256 bytes) and a
+    // level is padded to a multiple of 256 bytes, so every (slot, ring row) offset fits the 256-byte
+    // granular offset fields of ds_read2st64_b32 / ds_write2st64_b32: one address register per
+    // x-shift serves all nine slots in all four phases, and the row loop has no LDS address
+    // arithmetic at all.  The window-edge lanes (whose results are nobody's input, see `care`) read
+    // their missing neighbour column from the adjacent slot row instead of a pad column: ordinary
+    // populations; FRONT bytes in front of level 1 give its first slot row a column -1.
+    static constexpr int PADC = LBM_TB_PADC;     // pad columns either side of a slot row (0; 1 = the older layout)
+    static constexpr int RW = W + 2 * PADC;      // floats per slot row
+    static constexpr int FRONT = 16;
     static constexpr int A_ROW = 3 * RW * 4;     // bytes per ring row of slots 0-2
     static constexpr int B_ROW = 6 * RW * 4;     // bytes per ring row of slots 3-8
     static constexpr int B_OFF = DA * A_ROW;
     static constexpr int F_OFF = B_OFF + 4 * B_ROW;          // flag bytes, ring of 4 rows of RW bytes
     static constexpr int E_OFF = (F_OFF + 4 * RW + 3) / 4 * 4;  // last column's slot 0, ring of 4 floats
-    static constexpr int LEVB = (E_OFF + 16 + 15) / 16 * 16;    // bytes per level
-    static constexpr int LDSB = (T - 1) * LEVB;
+    static constexpr int LEVB = PADC ? (E_OFF + 16 + 15) / 16 * 16 : (E_OFF + 16 + 255) / 256 * 256;  // bytes per level
+    static constexpr int LDSB = FRONT + (T - 1) * LEVB + 16;
+    static_assert(LDSB <= 160 * 1024, "LDS image too large");
     static constexpr int NW = T * NB / CPL;      // waves: one per (stage, CPL blocks)
     // byte offset of population slot sl in the ring row written `age` iterations before phase ph
     static constexpr int slot_off(int sl, int ph, int age) {
