@@ -269,6 +269,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         // that the ambient values need no registers in the row loop (a spilled scalar would be
         // reloaded there by a vmem load whose in-order vmcnt wait drains the stage-1 prefetch)
         if (ob_u) {
+            asm volatile("; top inlet");  // keeps hipcc from turning the branch into selects in every row
 #pragma unroll
             for (int k = 0; k < Q; k++) {
                 if (dy_of(k) != 1) continue;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
 #pragma unroll
         for (int c = 0; c < CPL; c++) blocked.set(c, rd_flag[C::flag_off(PH, 2) + 64 * c]);
         if (ob_u) {  // top inlet, wave-uniform and rare (see inlet_fix)
+            asm volatile("; top inlet");  // keeps hipcc from turning the branch into selects in every row
 #pragma unroll
             for (int k = 0; k < Q; k++) {
                 if (dy_of(k) != 1) continue;

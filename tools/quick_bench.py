@@ -19,6 +19,11 @@ def main():
     s.set_surroundings(onp.ambient())
     s.set_tuning(tb_max, tb_rows)
     s.init_equilibrium(100.0, (0.0, 0.1), amp=0.01, seed=0)
+    if len(sys.argv) > 10 and sys.argv[10] == "yeet":  # the reference's yeet.png mask, tiled (bench.py's config 3)
+        z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "masks.npz"))
+        sh = tuple(int(v) for v in z["yeet_shape"])
+        yeet = np.unpackbits(z["yeet_bits"])[:sh[0] * sh[1]].reshape(sh)
+        s.upload_blocked(np.tile(yeet, (-(-N // sh[0]), -(-M // sh[1])))[:N, :M])
     s.fused_collide_stream(3)
     s.sync()
     for rep in range(3):
