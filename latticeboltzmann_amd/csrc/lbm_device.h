@@ -412,6 +412,54 @@ __device__ __forceinline__ bool relax_is_identity2(const f2 a[Q], f2 p, f2 c, la
     return (~(ok0 & ok1) & ballot(true)) == 0;
 }
 
+// Moments for the tiny-omega common path: the same pairwise / sequential sums as moments2(), and
+// the two quotients by the refinement v_div_scale / v_div_fmas run when they scale the NUMERATOR by
+// 2^64 -- unconditionally, with no test of the operands' exponents.  Valid (bit-identical to the
+// IEEE quotient wherever a bit of it can matter) under the conditions ordinary2() checks afterwards:
+// every population non-negative and 2^-60 <= p <= 2^39.  Then |m| <= 5 max a_k <= 5p < 2^42, the
+// scaled numerator n = m 2^64 is exact and either zero or in [2^-85, 2^106], r = 1/p (one
+// Newton step on v_rcp_f32) is normal, q0 = n r >= 2^-125 is normal, and every residual
+// fma(-p, q, n) is a multiple of 2^(E_n - 47) >= 2^-132: no underflow anywhere, so q2 = RN(n / p)
+// as in the hardware's own scaled expansion.  u = q2 2^-64 is exact unless |u| < 2^-126; there a
+// second rounding can move the last denormal bit, which nothing downstream can see: with
+// |u0| < 2^-126 the sums u0 +- u1 equal the IEEE ones unless |u1| < 2^-124 too, and then all of
+// 3 e.u, 4.5 (e.u)^2 and c vanish against the 1 they are added to (|e.u| < 2^-123).
+__device__ __forceinline__ void moments2_scaled(const f2 a[Q], f2& p, f2& u0, f2& u1) {
+    p = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + a[8];
+    f2 m0 = 0.0f - a[0];
+    m0 = m0 + a[2]; m0 = m0 - a[3]; m0 = m0 + a[5]; m0 = m0 - a[6]; m0 = m0 + a[8];
+    f2 m1 = 0.0f - a[0];
+    m1 = m1 - a[1]; m1 = m1 - a[2]; m1 = m1 + a[6]; m1 = m1 + a[7]; m1 = m1 + a[8];
+    const f2 r0 = f2{__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
+    const f2 one = f2{1.0f, 1.0f};
+    const float up = 18446744073709551616.0f /* 2^64 */, down = 5.421010862427522e-20f /* 2^-64 */;
+    f2 e = __builtin_elementwise_fma(-p, r0, one);
+    const f2 r = __builtin_elementwise_fma(e, r0, r0);
+    f2 n = m0 * up;
+    f2 q = n * r;
+    e = __builtin_elementwise_fma(-p, q, n);
+    q = __builtin_elementwise_fma(e, r, q);
+    e = __builtin_elementwise_fma(-p, q, n);
+    u0 = __builtin_elementwise_fma(e, r, q) * down;
+    n = m1 * up;
+    q = n * r;
+    e = __builtin_elementwise_fma(-p, q, n);
+    q = __builtin_elementwise_fma(e, r, q);
+    e = __builtin_elementwise_fma(-p, q, n);
+    u1 = __builtin_elementwise_fma(e, r, q) * down;
+}
+// The conditions of moments2_scaled() and of relax_is_identity() in one vote over the lanes that
+// matter (cm = ballot(care)): sign bits clear, 2^-60 <= p <= 2^39, c <= 1/8.
+__device__ __forceinline__ bool ordinary2(const f2 a[Q], f2 p, f2 c, lanemask cm0, lanemask cm1) {
+    unsigned sx = __float_as_uint(a[0].x), sy = __float_as_uint(a[0].y);
+#pragma unroll
+    for (int k = 1; k < Q; k++) { sx |= __float_as_uint(a[k].x); sy |= __float_as_uint(a[k].y); }
+    const float lo = 8.673617379884035e-19f /* 2^-60 */, hi = 549755813888.0f /* 2^39 */;
+    const lanemask good0 = ballot((int)sx >= 0) & ballot(p.x >= lo) & ballot(p.x <= hi) & ballot(c.x <= 0.125f);
+    const lanemask good1 = ballot((int)sy >= 0) & ballot(p.y >= lo) & ballot(p.y <= hi) & ballot(c.y <= 0.125f);
+    return (~((~cm0 | good0) & (~cm1 | good1)) & ballot(true)) == 0;
+}
+
 // The result is handed to `sink(const f2 out[Q])` instead of being returned: the common case (tiny
 // omega, ordinary cells, no obstacle in the wave) passes eq[] on as it is, every other case
 // corrects eq[] inside ONE rare, wave-uniform branch and calls the sink from there.  Returned
@@ -420,12 +468,25 @@ __device__ __forceinline__ bool relax_is_identity2(const f2 a[Q], f2 p, f2 c, la
 template <class Sink>
 __device__ __forceinline__ void collide2_to(const f2 a[Q], bool b0, bool b1, lanemask bm0, lanemask bm1,
                                             const Omega& om, lanemask cm0, lanemask cm1, Sink sink) {
+    const bool obstacle = (bm0 | bm1) != 0;
+    // The common case first and on its own: tiny omega, no obstacle in the wave, ordinary cells.
+    if (om.tiny & !obstacle) {
+        f2 p, u0, u1, eq[Q];
+        moments2_scaled(a, p, u0, u1);
+        const f2 c = equilibrium2(u0, u1, p, eq);
+        if (__builtin_expect(ordinary2(a, p, c, cm0, cm1), 1)) {
+            asm volatile("; collide2_to: common path");
+            sink(eq);
+            asm volatile("; collide2_to: common path end");
+            return;
+        }
+    }
+    // Everything else, for every input
     f2 p, u0, u1, eq[Q];
     moments2(a, p, u0, u1);
     const f2 c = equilibrium2(u0, u1, p, eq);
     // both votes evaluated unconditionally and joined bitwise: one wave-uniform branch
     const bool fast = om.tiny & relax_is_identity2(a, p, c, bm0, bm1, cm0, cm1);
-    const bool obstacle = (bm0 | bm1) != 0;
     if (__builtin_expect(!fast | obstacle, 0)) {
         if (fast) {  // only blocked cells relax (omega = 1: exact in either product)
 #pragma unroll
@@ -450,11 +511,13 @@ __device__ __forceinline__ void collide2_to(const f2 a[Q], bool b0, bool b1, lan
                 eq[k] = v + eq[k];
             }
         }
-        asm volatile("; collide2_to: general path");  // keeps the two sink copies from being merged again
+        asm volatile("; collide2_to: general path");  // (the markers keep the sink copies from being merged again)
         sink(eq);
+        asm volatile("; collide2_to: general path end");
     } else {
-        asm volatile("; collide2_to: common path");
+        asm volatile("; collide2_to: tiny omega, extreme exponents");
         sink(eq);
+        asm volatile("; collide2_to: tiny omega, extreme exponents end");
     }
 }
 __device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, const Omega& om,

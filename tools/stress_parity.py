@@ -36,12 +36,21 @@ def main():
             # populations, flow fast enough for 1.5 |u|^2 > 1/8
             for _ in range(int(rng.integers(1, 4))):
                 y, x = int(rng.integers(0, N - 2)), int(rng.integers(0, M - 4))
-                kind = int(rng.integers(0, 5))
+                kind = int(rng.integers(0, 7))
                 if kind == 0: cells[y:y + 2, x:x + 4] *= np.float32(-1)
                 elif kind == 1: cells[y:y + 2, x:x + 4] = 0
                 elif kind == 2: cells[y:y + 2, x:x + 4] *= np.float32(1e32)
                 elif kind == 3: cells[y:y + 2, x:x + 4] *= np.float32(1e-33)
-                else: cells[y:y + 2, x:x + 4] = onp.getEquilibrium(np.float32([[0.3, 0.35]]), np.float32([90]))[0]
+                elif kind == 4: cells[y:y + 2, x:x + 4] = onp.getEquilibrium(np.float32([[0.3, 0.35]]), np.float32([90]))[0]
+                elif kind == 5:
+                    # momentum sums far below the density: only the rest population is ordinary, the
+                    # moving ones are tiny or denormal (numerators of 2^-100 .. 2^-149 over p ~ 1)
+                    t = rng.random((2, 4, 9)).astype(np.float32) * np.float32(2.0) ** np.float32(-int(rng.integers(100, 127)))
+                    t[..., 4] = np.float32(rng.uniform(0.5, 200))
+                    cells[y:y + 2, x:x + 4] = t
+                else:
+                    # densities at the ends of the window the fast quotient accepts (2^-60 .. 2^39)
+                    cells[y:y + 2, x:x + 4] *= np.float32(2.0) ** np.float32(int(rng.choice([-67, -66, -65, 31, 32, 33])))
         u_amb = np.array([[rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.3)]], np.float32)
         surr = np.ascontiguousarray(onp.getEquilibrium(u_amb, np.array([100], np.float32))[0], dtype=np.float32)
         s = Solver(N, M, omega, inner_timesteps=T, boundary=boundary)
