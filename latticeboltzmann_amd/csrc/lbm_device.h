@@ -488,12 +488,13 @@ __device__ __forceinline__ void collide2_to(const f2 a[Q], bool b0, bool b1, lan
     // both votes evaluated unconditionally and joined bitwise: one wave-uniform branch
     const bool fast = om.tiny & relax_is_identity2(a, p, c, bm0, bm1, cm0, cm1);
     if (__builtin_expect(!fast | obstacle, 0)) {
-        if (fast) {  // only blocked cells relax (omega = 1: exact in either product)
+        if (fast) {
+            // only blocked cells relax, with omega = 1.  fma(a - eq, o, eq) with o = 1 (blocked) or
+            // 0 (free): the product by 0 or 1 is exact, so the fma rounds exactly once, like the
+            // reference's separate multiply and add, and o = 0 returns eq (a - eq is finite here)
+            const f2 o = f2{b0 ? 1.0f : 0.0f, b1 ? 1.0f : 0.0f};
 #pragma unroll
-            for (int k = 0; k < Q; k++) {
-                const f2 v = (a[k] - eq[k]) + eq[k];
-                eq[k] = f2{b0 ? v.x : eq[k].x, b1 ? v.y : eq[k].y};
-            }
+            for (int k = 0; k < Q; k++) eq[k] = __builtin_elementwise_fma(a[k] - eq[k], o, eq[k]);
         } else if (om.f32_exact) {  // wave-uniform
             const f2 o = f2{b0 ? 1.0f : om.f, b1 ? 1.0f : om.f};
 #pragma unroll
