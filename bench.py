@@ -127,7 +127,7 @@ def main():
         backend = os.environ.get("LBM_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             from latticeboltzmann_amd.slabs import init_process_group_rccl
-            init_process_group_rccl(local_rank)  # RCCL's stream at high priority
+            init_process_group_rccl(local_rank)
         else:
             dist.init_process_group(backend)
 

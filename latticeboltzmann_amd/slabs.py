@@ -23,14 +23,19 @@ from . import lb_hip_kernel as hk
 
 
 def init_process_group_rccl(device, **kw):
-    """torch.distributed over RCCL (backend "nccl") for the halo exchange, with RCCL's own stream
-    at high priority: its send/recv kernels must not queue behind the million-workgroup interior
-    launch they are meant to overlap with.  kw: init_method / rank / world_size when not taken
-    from the torchrun environment."""
+    """torch.distributed over RCCL (backend "nccl") for the halo exchange, bound to `device` at once
+    (eager communicator).  kw: init_method / rank / world_size when not taken from the torchrun
+    environment.
+
+    Stream priorities are deliberately left alone.  Round 2 tried RCCL's own stream and the
+    communication stream at high priority, so that the halo messages would not queue behind the
+    interior launch they overlap with; on this runtime (ROCm 7.x, 4 hardware queues per process)
+    either of the two made the schedule hang now and then -- 4 of 4 randomised soaks
+    (tools/stress_slabs.py) stopped within 70 cases with the compute stream waiting for ever,
+    against 0 of 500 cases with default priorities -- and the measured gain had been 0.1 %."""
     import torch
     import torch.distributed as dist
-    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-    dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"), pg_options=opts, **kw)
+    dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"), **kw)
     return dist
 
 
@@ -140,10 +145,7 @@ class SlabSolver:
         if M < 8 or self.N < 16:  # the LDS kernel does not take grids this small
             self.tb_max_depth = 1
         self.compute = torch.cuda.Stream(device=self.device)
-        # high priority: what runs on it (copies, event waits; RCCL's kernels run on RCCL's own
-        # stream, which bench.py also asks to be a high-priority one) must not queue behind the
-        # interior launch it overlaps with
-        self.comm = torch.cuda.Stream(device=self.device, priority=-1)
+        self.comm = torch.cuda.Stream(device=self.device)  # default priority: see init_process_group_rccl
         self.solver.set_stream(self.compute.cuda_stream)
         self._tensors = {}
         self._fresh = True
