@@ -86,6 +86,13 @@
 #ifndef LBM_TB_REMAP
 #define LBM_TB_REMAP 1
 #endif
+// Workgroup -> XCD mapping at depth 4 with fp32 storage (the depth that sits on the HBM ceiling of
+// this access pattern): plain round-robin, i.e. all eight XCDs march down the SAME band of rows,
+// is 2.8 % faster there than one band per XCD (same-box A/B: 276 against 268 GLUPS; T = 2: -3.6 %,
+// T = 3: 0, T = 5 / 6: -1..2 %, fp16: -0.5 %).
+#ifndef LBM_TB_REMAP4
+#define LBM_TB_REMAP4 0
+#endif
 #ifndef LBM_TB_PADINIT
 #define LBM_TB_PADINIT 1
 #endif
@@ -110,10 +117,11 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDSB];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const unsigned wg = LBM_TB_REMAP == 1 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    constexpr int REMAP = (T == 4 && std::is_same<ST, float>::value) ? LBM_TB_REMAP4 : LBM_TB_REMAP;
+    const unsigned wg = REMAP == 1 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int nchunks_ = gridDim.x / nstrips;
-    const int strip = LBM_TB_REMAP == 2 ? wg / nchunks_ : wg % nstrips;
-    const int chunk = LBM_TB_REMAP == 2 ? wg % nchunks_ : wg / nstrips;
+    const int strip = REMAP == 2 ? wg / nchunks_ : wg % nstrips;
+    const int chunk = REMAP == 2 ? wg % nchunks_ : wg / nstrips;
     const int xo = strip * C::SW;  // first stored column
     const int y0 = row0 + chunk * Ry;
     const int y1 = min(y0 + Ry, row0 + nrows);
