@@ -469,12 +469,25 @@ template <class Sink>
 __device__ __forceinline__ void collide2_to(const f2 a[Q], bool b0, bool b1, lanemask bm0, lanemask bm1,
                                             const Omega& om, lanemask cm0, lanemask cm1, Sink sink) {
     const bool obstacle = (bm0 | bm1) != 0;
-    // The common case first and on its own: tiny omega, no obstacle in the wave, ordinary cells.
-    if (om.tiny & !obstacle) {
+    // The common case first and on its own: tiny omega, ordinary cells (blocked ones included, so
+    // that their moments are exact too).  Free cells: eq is the result.  Blocked cells (rare: a
+    // wave-uniform branch) relax with omega = 1, written as fma(a - eq, o, eq) with o = 1 (blocked)
+    // or 0 (free): the product is exact, so the fma rounds once like the reference's separate
+    // multiply and add, and o = 0 returns eq (a - eq is finite for an ordinary cell).
+    if (om.tiny) {
         f2 p, u0, u1, eq[Q];
         moments2_scaled(a, p, u0, u1);
         const f2 c = equilibrium2(u0, u1, p, eq);
         if (__builtin_expect(ordinary2(a, p, c, cm0, cm1), 1)) {
+            if (obstacle) {
+                const f2 o = f2{b0 ? 1.0f : 0.0f, b1 ? 1.0f : 0.0f};
+#pragma unroll
+                for (int k = 0; k < Q; k++) eq[k] = __builtin_elementwise_fma(a[k] - eq[k], o, eq[k]);
+                asm volatile("; collide2_to: common path, obstacle in the wave");
+                sink(eq);
+                asm volatile("; collide2_to: common path, obstacle in the wave end");
+                return;
+            }
             asm volatile("; collide2_to: common path");
             sink(eq);
             asm volatile("; collide2_to: common path end");
