@@ -340,6 +340,20 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         if (std::is_same<ST, __half>::value) return __half2float(__float2half_rn(v));
         return v;
     };
+    // the same for a lane's value(s): two cells go through one packed conversion (v_cvt_pk_f16_f32,
+    // round to nearest even like __float2half_rn)
+    auto ring_round = [&](V v) {
+        if (!std::is_same<ST, __half>::value) return v;
+        if constexpr (CPL == 2) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            return __builtin_convertvector(__builtin_convertvector(v, h2), V);
+        } else {
+            float x[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; c++) x[c] = ring_value(L::get(v, c));
+            return L::make(x);
+        }
+    };
     auto to_lds = [&](auto xedge, auto ph, int q, const V* a, const Flags<CPL>& blocked) {
         constexpr int PH = decltype(ph)::value;
         if (XMODE != XMODE_PERIODIC && q == qhi) {
@@ -359,9 +373,10 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         }
 #pragma unroll
         for (int k = 0; k < Q; k++) {
+            const V rv = ring_round(a[k]);
 #pragma unroll
             for (int c = 0; c < CPL; c++)
-                *reinterpret_cast<float*>(wr_base + C::slot_off(slot_of(k), PH, 0) + 256 * c) = ring_value(L::get(a[k], c));
+                *reinterpret_cast<float*>(wr_base + C::slot_off(slot_of(k), PH, 0) + 256 * c) = L::get(rv, c);
         }
 #pragma unroll
         for (int c = 0; c < CPL; c++) wr_flag[C::flag_off(PH, 0) + 64 * c] = (unsigned char)blocked.raw[c];
