@@ -34,8 +34,10 @@
 #include "lbm_internal.h"
 
 // Window width (NB 64-column blocks), cells per
-// lane and margin for each launch depth, from sweeps on MI355X at 16384 x 16384 (periodic /
-// reference edges): T=2 143 / 146, T=3 213 / 210, T=4 249 / 237, T=5 241 / 222, T=6 274 / 253 GLUPS.
+// lane and margin for each launch depth, from sweeps on MI355X at 16384 x 16384.  GLUPS, periodic /
+// reference edges, round 1: T=2 143 / 146, T=3 213 / 210, T=4 249 / 237, T=5 241 / 222, T=6 274 / 253;
+// end of round 2 (the common-case collide of lbm_device.h, immediate-only LDS addressing, ...):
+// T=2 143, T=3 215, T=4 276 / 266, T=5 279, T=6 318 / 300 (profiles/r02_tb_experiments.md).
 #ifndef LBM_TB_NB2
 #define LBM_TB_NB2 12
 #define LBM_TB_CPL2 2

@@ -329,3 +329,53 @@ def test_tiny_omega_shortcut_is_exact(omega, T):
         onp.run(refn, blocked, 3 * T, omega, surr, "periodic")
     assert np.array_equal(refn, ref, equal_nan=True)
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [1, 4, 6])
+def test_common_path_window_ends_and_tiny_momentum(T):
+    """The LDS kernel's common path (lbm_device.h: moments2_scaled / ordinary2 / collide2_to) takes
+    the quotients u = m / p from a numerator-scaled refinement with no test of the operands'
+    exponents, accepted by one vote: sign bits clear, 2^-60 <= p <= 2^39, 1.5|u|^2 <= 1/8.  Scene:
+    densities either side of both window ends, momentum sums of 2^-100 .. 2^-149 (denormal) over
+    p ~ 1 (only the rest population ordinary), u0 = 0 exactly, blocked cells holding values that are
+    not ordinary (zero, negative, huge) next to ordinary free cells -- against the oracle, bit for bit."""
+    from latticeboltzmann_amd.lb_hip_kernel import Solver
+    N, M = 40, 768
+    rng = np.random.default_rng(23)
+    blocked = rng.random((N, M)) < 0.01
+    cells = onp.perturbed_cells(N, M, seed=3, amp=0.1)
+    for j, e in enumerate([-68, -67, -66, -65, 30, 31, 32, 33]):   # p = 100 * 2^e around 2^-60 and 2^39
+        cells[:, 64 * j:64 * j + 40] *= np.float32(2.0) ** np.float32(e)
+    t = rng.random((N, 64, 9)).astype(np.float32)                   # tiny momentum sums over p ~ 1
+    t *= (np.float32(2.0) ** -rng.integers(100, 127, size=(N, 64, 1))).astype(np.float32)
+    t[..., 4] = rng.uniform(0.5, 200, size=(N, 64)).astype(np.float32)
+    cells[:, 512:576] = t
+    sym = cells[:, 576:640].copy()                                  # u0 = 0 exactly: k <-> mirrored in y
+    for k in range(9):
+        ky = 3 * (k // 3) + (2 - k % 3)
+        sym[..., ky] = cells[:, 576:640, k]
+    cells[:, 576:640] = np.float32(0.5) * (sym + cells[:, 576:640])
+    blocked[10:14, 640:704] = True                                  # blocked cells out of the ordinary
+    cells[10, 640:704] = 0
+    cells[11, 640:704] *= np.float32(-1)
+    cells[12, 640:704] *= np.float32(1e30)
+    cells[13, 640:704, 2] = -0.0
+    surr = onp.ambient()
+    s = Solver(N, M, 1e-14, inner_timesteps=T, boundary="periodic")
+    s.set_tuning(6, 0)
+    s.set_surroundings(surr)
+    s.upload_blocked(blocked)
+    s.upload_cells(cells)
+    ref = cells.copy()
+    with np.errstate(all="ignore"):
+        for _ in range(3):
+            s.fused_collide_stream(1)
+            oc.run(ref, blocked, T, 1e-14, surr, "periodic")
+            got = s.read_cells()
+            bad = np.argwhere(~((got == ref) | (np.isnan(got) & np.isnan(ref))))
+            assert bad.size == 0, f"T={T}: {len(bad)} mismatches, first {bad[:5].tolist()}"
+        refn = cells.copy()
+        onp.run(refn, blocked, 3 * T, 1e-14, surr, "periodic")
+    assert np.array_equal(refn, ref, equal_nan=True)
+    s.close()
