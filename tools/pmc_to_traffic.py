@@ -30,8 +30,9 @@ def per_kernel(path):
 
 def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-    fetch, frows = per_kernel(glob.glob(os.path.join(src, "fetch", "*", "*_counter_collection.csv"))[0])
-    write, wrows = per_kernel(glob.glob(os.path.join(src, "write", "*", "*_counter_collection.csv"))[0])
+    newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)  # a directory may hold several passes
+    fetch, frows = per_kernel(newest(os.path.join(src, "fetch", "*", "*_counter_collection.csv")))
+    write, wrows = per_kernel(newest(os.path.join(src, "write", "*", "*_counter_collection.csv")))
     keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size",
             "VGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
     csv_name = f"{tag}_bench_pmc_fetch_write.csv"
