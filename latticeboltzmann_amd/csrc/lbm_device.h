@@ -78,7 +78,7 @@ constexpr double OMEGA_TINY_MAX = 1.0 / 17179869184.0;  // 2^-34 = 5.8e-11 (the 
 // w (double, rounded to float; or the plain fp32 product) has |w| <= p * 2^-34 * (1 + 2^-23) + 2^-149
 // < 2^-26 * 0.010413 p <= 2^-26 eq_k < ulp(eq_k) / 4.  A float whose neighbours are at least
 // ulp/2 away (ulp/4 towards zero at a power of two) absorbs such a w: fl(w + eq_k) = eq_k.  QED
-// The test is wave-uniform (__all); blocked cells (omega = 1: (a - eq) + eq, the product by 1 is
+// The test is wave-uniform (a vote of all lanes); blocked cells (omega = 1: (a - eq) + eq, the product by 1 is
 // exact) are handled lane by lane inside the shortcut; a wave with a free cell
 // outside (1)-(3) -- zero density, negative or non-finite populations, |u| > 0.29 -- takes the
 // general path, so results are bit-identical for every input.

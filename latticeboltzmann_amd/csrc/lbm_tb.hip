@@ -471,7 +471,8 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
             }
         }
     };
-    // The pad columns either side of a ring row are never written, yet the window-edge lanes of the
+    // Only the older layout with pad columns (LBM_TB_PADC = 1; the default has none, lbm_tb_common.h):
+    // the pad columns either side of a ring row are never written, yet the window-edge lanes of the
     // next level read them (their results are nobody's input).  Give them an ordinary value once:
     // stale LDS there could hold anything, and one non-finite or zero-density lane sends its whole
     // wave down the exact-division path (and, for tiny omega, the general relaxation) in every row.
