@@ -542,6 +542,73 @@ __device__ __forceinline__ void collide2(f2 a[Q], bool b0, bool b1, const Omega&
     });
 }
 
+// --- one cell per lane: the same common path for the T = 1 kernel ---------------------------------
+// moments2_scaled() / ordinary2() / collide2_to() for a single cell per lane (see there for the
+// conditions and the proof).
+__device__ __forceinline__ void moments_scaled(const float a[Q], float& p, float& u0, float& u1) {
+    p = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) + a[8];
+    float m0 = 0.0f - a[0];
+    m0 = m0 + a[2]; m0 = m0 - a[3]; m0 = m0 + a[5]; m0 = m0 - a[6]; m0 = m0 + a[8];
+    float m1 = 0.0f - a[0];
+    m1 = m1 - a[1]; m1 = m1 - a[2]; m1 = m1 + a[6]; m1 = m1 + a[7]; m1 = m1 + a[8];
+    const float r0 = __builtin_amdgcn_rcpf(p);
+    const float up = 18446744073709551616.0f /* 2^64 */, down = 5.421010862427522e-20f /* 2^-64 */;
+    float e = __builtin_fmaf(-p, r0, 1.0f);
+    const float r = __builtin_fmaf(e, r0, r0);
+    float n = m0 * up;
+    float q = n * r;
+    e = __builtin_fmaf(-p, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-p, q, n);
+    u0 = __builtin_fmaf(e, r, q) * down;
+    n = m1 * up;
+    q = n * r;
+    e = __builtin_fmaf(-p, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-p, q, n);
+    u1 = __builtin_fmaf(e, r, q) * down;
+}
+__device__ __forceinline__ bool ordinary(const float a[Q], float p, float c) {
+    unsigned sg = __float_as_uint(a[0]);
+#pragma unroll
+    for (int k = 1; k < Q; k++) sg |= __float_as_uint(a[k]);
+    const float lo = 8.673617379884035e-19f /* 2^-60 */, hi = 549755813888.0f /* 2^39 */;
+    const lanemask good = ballot((int)sg >= 0) & ballot(p >= lo) & ballot(p <= hi) & ballot(c <= 0.125f);
+    return (~good & ballot(true)) == 0;
+}
+// collide of one cell per lane (a[] already reflected), result handed to sink(const float out[Q]).
+// bm = ballot(blocked), taken where `blocked` is computed.
+template <class Sink>
+__device__ __forceinline__ void collide_to(const float a[Q], bool blocked, lanemask bm, const Omega& om, Sink sink) {
+    if (om.tiny) {
+        float p, u0, u1, eq[Q];
+        moments_scaled(a, p, u0, u1);
+        const float c = equilibrium(u0, u1, p, eq);
+        if (__builtin_expect(ordinary(a, p, c), 1)) {
+            if (bm != 0) {  // blocked cells relax with omega = 1: one fma, see collide2_to
+                const float o = blocked ? 1.0f : 0.0f;
+#pragma unroll
+                for (int k = 0; k < Q; k++) eq[k] = __builtin_fmaf(a[k] - eq[k], o, eq[k]);
+                asm volatile("; collide_to: common path, obstacle in the wave");
+                sink(eq);
+                asm volatile("; collide_to: common path, obstacle in the wave end");
+                return;
+            }
+            asm volatile("; collide_to: common path");
+            sink(eq);
+            asm volatile("; collide_to: common path end");
+            return;
+        }
+    }
+    float b[Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) b[k] = a[k];
+    collide(b, blocked, om);
+    asm volatile("; collide_to: general path");
+    sink(b);
+    asm volatile("; collide_to: general path end");
+}
+
 // --- kernel-semantics compatibility mode (XMODE_CUDA) -----------------------------
 // What the reference's CUDA kernel computes where it differs from its numpy path, restated in IEEE
 // fp32 in the kernel's operation order (oracle: oracle/lbm_numpy.py cuda_kernel_step; PARITY-

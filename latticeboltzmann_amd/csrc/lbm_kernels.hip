@@ -46,8 +46,16 @@ __global__ __launch_bounds__(256) void step_kernel(const T* __restrict__ gin, T*
         for (int k = 0; k < Q; k++) a[k] = gate ? b[k] : a[k];
     } else {
         pull<XMODE, T, LBM_T1_NT_LOADS>(gin, geo, y, xb, lane, a);
+        const lanemask bm = ballot(blocked);
         reflect(a, blocked);
-        collide(a, blocked, omega_of(geo));
+        collide_to(a, blocked, bm, omega_of(geo), [&](const float* out) {
+            if (xb * LANES + lane < geo.M) {
+                T* o = gout + (long long)(y + geo.G) * geo.rowStride + (long long)xb * CHUNK + lane;
+#pragma unroll
+                for (int k = 0; k < Q; k++) st_nt(o + slot_of(k) * LANES, out[k]);
+            }
+        });
+        return;
     }
 
     if (xb * LANES + lane < geo.M) {
