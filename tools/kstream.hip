@@ -1,0 +1,134 @@
+// Development micro-benchmark: what makes a streaming copy slow on MI355X -- long-lived waves, each
+// wave owning a contiguous stream, or bursts?  All variants move the same 2 x 9.66 GB in 2304-byte
+// chunks (nine 256-byte dword-per-lane loads and stores per chunk, non-temporal), 256 threads per
+// workgroup, residency capped by an unused dynamic-LDS request.
+//   short      one chunk per wave, grid = all chunks (the T=1 kernel's shape)
+//   long/sweep persistent waves; in step i the grid's waves cover one contiguous span, then advance
+//   long/own   persistent waves; each wave copies its own contiguous run of chunks
+//   long/wg    persistent waves; each WORKGROUP owns a contiguous run, its waves interleaved
+//   PF         chunks loaded ahead of the one being stored (register prefetch)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+enum { SHORT = 0, SWEEP = 1, OWN = 2, WG = 3, SPLIT = 4, LOCK = 5 };  // LOCK: sweep with a soft (bounded-spin) grid-wide rendezvous every SYNC_EVERY steps  // SPLIT: sweep, odd waves only load, even waves only store
+
+__device__ unsigned g_arrived;
+template <int MODE, int PF>
+__global__ __launch_bounds__(256) void kstream(const float* __restrict__ in, float* __restrict__ out,
+                                               long long nchunks, int iters, int sync_every, unsigned arrive_base) {
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    auto chunk_of = [&](int it) -> long long {
+        if (MODE == SHORT) return gw;
+        if (MODE == SWEEP || MODE == LOCK) return (long long)it * nw + gw;
+        if (MODE == SPLIT) return (long long)it * (nw / 2) + gw / 2;
+        if (MODE == OWN) return gw * iters + it;
+        return ((long long)blockIdx.x * iters + it) * 4 + (threadIdx.x >> 6);  // WG: 4 chunks per step
+    };
+    float v[PF + 1][9];
+    auto load = [&](int it, float* d) {
+        if (MODE == SPLIT && !(gw & 1)) {  // a storing wave: nothing to load
+#pragma unroll
+            for (int k = 0; k < 9; k++) d[k] = (float)(it + k);
+            return;
+        }
+        long long c = chunk_of(it);
+        c = c < nchunks ? c : nchunks - 1;
+        const float* p = in + c * 576 + lane;
+#pragma unroll
+        for (int k = 0; k < 9; k++) d[k] = __builtin_nontemporal_load(p + 64 * k);
+    };
+    auto store = [&](int it, const float* d) {
+        const long long c = chunk_of(it);
+        if (c >= nchunks) return;
+        if (MODE == SPLIT && (gw & 1)) {  // a loading wave: consume the values, store (almost) never
+            float s = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) s += d[k];
+            if (s == 1.2345e-30f) out[c * 576 + lane] = s;
+            return;
+        }
+        float* p = out + c * 576 + lane;
+#pragma unroll
+        for (int k = 0; k < 9; k++) __builtin_nontemporal_store(d[k], p + 64 * k);
+    };
+#pragma unroll
+    for (int d = 0; d < PF; d++) load(d, v[d]);
+    // PF+1 register sets, rotated by unrolling the loop PF+1 times
+    for (int it = 0; it < iters; it += PF + 1) {
+        if (MODE == LOCK && it > 0 && it % sync_every == 0) {
+            // never a hang: a workgroup that has waited 20000 polls goes on alone
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(&g_arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned want = arrive_base + (unsigned)(it / sync_every) * gridDim.x;
+                for (int spin = 0; spin < 20000; spin++)
+                    if ((int)(__hip_atomic_load(&g_arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) break;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u <= PF; u++) {
+            if (it + u < iters) {
+                if (it + u + PF < iters + 0) load(it + u + PF, v[(u + PF) % (PF + 1)]);
+                store(it + u, v[u]);
+            }
+        }
+    }
+}
+
+static unsigned g_base = 0;
+template <int MODE, int PF>
+static int run(const char* name, const float* a, float* b, long long nchunks, int wg_per_cu, unsigned lds, int rounds, int sync_every = 8) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    unsigned grid; int iters;
+    if (MODE == SHORT) { grid = (unsigned)((nchunks + 3) / 4); iters = 1; }
+    else if (MODE == SPLIT) { grid = 256u * wg_per_cu; iters = (int)((nchunks + grid * 2ll - 1) / (grid * 2ll)); }
+    else if (wg_per_cu < 0) { iters = -wg_per_cu; grid = (unsigned)((nchunks + 4ll * iters - 1) / (4ll * iters)); }  // medium-lived waves
+    else { grid = 256u * wg_per_cu; iters = (int)((nchunks + grid * 4ll - 1) / (grid * 4ll)); }
+    std::vector<float> t;
+    for (int r = 0; r < rounds + 1; r++) {
+        CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; i++) {
+            hipLaunchKernelGGL((kstream<MODE, PF>), dim3(grid), dim3(256), lds, 0, a, b, nchunks, iters, sync_every, g_base);
+            if (MODE == LOCK) g_base += (unsigned)((iters - 1) / sync_every) * grid;  // arrivals this launch adds (iters not a multiple of PF+1 aside)
+        }
+        CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r) t.push_back(ms / 5);
+    }
+    std::sort(t.begin(), t.end());
+    printf("%-22s PF=%d  %d WG/CU (LDS %6u): %.3f ms  %.3f TB/s\n", name, PF, wg_per_cu, lds, t[t.size() / 2],
+           2.0 * nchunks * 2304 / t[t.size() / 2] / 1e9);
+    fflush(stdout);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const long long nchunks = 16384ll * 256;  // 16384 x 16384 cells
+    const int rounds = argc > 1 ? atoi(argv[1]) : 5;
+    float *a, *b;
+    CHECK(hipMalloc(&a, nchunks * 2304)); CHECK(hipMalloc(&b, nchunks * 2304));
+    CHECK(hipMemset(a, 0, nchunks * 2304));
+    const struct { int wg; unsigned lds; } caps[] = {{4, 36u << 10}, {6, 26u << 10}, {3, 53u << 10}, {2, 80u << 10}};
+    if (argc > 2)  // a soft grid-wide rendezvous every k steps: 0.3-3 TB/s, the rendezvous itself is what one measures
+        for (int k : {1, 2, 4, 8, 32}) run<LOCK, 0>("long/sweep lockstep", a, b, nchunks, 4, 36u << 10, rounds, k);
+    for (int it : {2, 4, 8, 16, 64}) run<SWEEP, 0>("sweep, iters per wave:", a, b, nchunks, -it, 36u << 10, rounds);
+    for (int it : {2, 8, 64}) run<OWN, 0>("own, iters per wave:", a, b, nchunks, -it, 36u << 10, rounds);
+    for (int wg : {4, 6, 8}) { run<SPLIT, 0>("long/split", a, b, nchunks, wg, wg == 4 ? 36u << 10 : wg == 6 ? 26u << 10 : 0, rounds); run<SPLIT, 1>("long/split", a, b, nchunks, wg, wg == 4 ? 36u << 10 : wg == 6 ? 26u << 10 : 0, rounds); run<SPLIT, 3>("long/split", a, b, nchunks, wg, wg == 4 ? 36u << 10 : wg == 6 ? 26u << 10 : 0, rounds); }
+    for (auto c : caps) {
+        if (c.wg != 4) continue;
+        run<SHORT, 0>("short", a, b, nchunks, c.wg, c.lds, rounds);
+        run<SWEEP, 0>("long/sweep", a, b, nchunks, c.wg, c.lds, rounds);
+        run<OWN, 0>("long/own", a, b, nchunks, c.wg, c.lds, rounds);
+        run<WG, 0>("long/wg", a, b, nchunks, c.wg, c.lds, rounds);
+        run<SWEEP, 1>("long/sweep", a, b, nchunks, c.wg, c.lds, rounds);
+        run<OWN, 1>("long/own", a, b, nchunks, c.wg, c.lds, rounds);
+        run<OWN, 3>("long/own", a, b, nchunks, c.wg, c.lds, rounds);
+        run<WG, 3>("long/wg", a, b, nchunks, c.wg, c.lds, rounds);
+    }
+    return 0;
+}
