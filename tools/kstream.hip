@@ -14,10 +14,10 @@
 #include <vector>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-enum { SHORT = 0, SWEEP = 1, OWN = 2, WG = 3, SPLIT = 4, LOCK = 5 };  // LOCK: sweep with a soft (bounded-spin) grid-wide rendezvous every SYNC_EVERY steps  // SPLIT: sweep, odd waves only load, even waves only store
+enum { SHORT = 0, SWEEP = 1, OWN = 2, WG = 3, SPLIT = 4, LOCK = 5, ROT = 6 };  // ROT: sweep, but which wave takes which chunk of the span changes every step  // LOCK: sweep with a soft (bounded-spin) grid-wide rendezvous every SYNC_EVERY steps  // SPLIT: sweep, odd waves only load, even waves only store
 
 __device__ unsigned g_arrived;
-template <int MODE, int PF>
+template <int MODE, int PF, int IO = 0>  // IO: 0 copy, 1 read only, 2 write only
 __global__ __launch_bounds__(256) void kstream(const float* __restrict__ in, float* __restrict__ out,
                                                long long nchunks, int iters, int sync_every, unsigned arrive_base) {
     const int lane = threadIdx.x & 63;
@@ -25,13 +25,14 @@ __global__ __launch_bounds__(256) void kstream(const float* __restrict__ in, flo
     auto chunk_of = [&](int it) -> long long {
         if (MODE == SHORT) return gw;
         if (MODE == SWEEP || MODE == LOCK) return (long long)it * nw + gw;
+        if (MODE == ROT) return (long long)it * nw + (gw + (long long)it * 1237) % nw;
         if (MODE == SPLIT) return (long long)it * (nw / 2) + gw / 2;
         if (MODE == OWN) return gw * iters + it;
         return ((long long)blockIdx.x * iters + it) * 4 + (threadIdx.x >> 6);  // WG: 4 chunks per step
     };
     float v[PF + 1][9];
     auto load = [&](int it, float* d) {
-        if (MODE == SPLIT && !(gw & 1)) {  // a storing wave: nothing to load
+        if (IO == 2 || (MODE == SPLIT && !(gw & 1))) {  // a storing wave: nothing to load
 #pragma unroll
             for (int k = 0; k < 9; k++) d[k] = (float)(it + k);
             return;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void kstream(const float* __restrict__ in, flo
     auto store = [&](int it, const float* d) {
         const long long c = chunk_of(it);
         if (c >= nchunks) return;
-        if (MODE == SPLIT && (gw & 1)) {  // a loading wave: consume the values, store (almost) never
+        if (IO == 1 || (MODE == SPLIT && (gw & 1))) {  // a loading wave: consume the values, store (almost) never
             float s = 0;
 #pragma unroll
             for (int k = 0; k < 9; k++) s += d[k];
@@ -80,8 +81,53 @@ __global__ __launch_bounds__(256) void kstream(const float* __restrict__ in, flo
     }
 }
 
+// four chunks per wave: dword-per-lane loads (the shape the lattice kernels need: one column per
+// lane), transposed through LDS, stored as nine 1-KB float4 instructions.  WIDE_LD: loads wide too.
+template <int WIDE_LD>
+__global__ __launch_bounds__(256) void kwide(const float* __restrict__ in, float* __restrict__ out, long long nchunks) {
+    __shared__ float lds[4][2304];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long c0 = ((long long)blockIdx.x * 4 + wave) * 4;
+    if (c0 >= nchunks) return;
+    const float* p = in + c0 * 576;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 w[9];
+    if (WIDE_LD) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) w[j] = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p) + j * 64 + lane);
+    } else {
+        float v[36];
+#pragma unroll
+        for (int j = 0; j < 36; j++) v[j] = __builtin_nontemporal_load(p + 64 * j + lane);
+#pragma unroll
+        for (int j = 0; j < 36; j++) lds[wave][64 * j + lane] = v[j];
+        // (one wave reads what it wrote itself: no barrier)
+#pragma unroll
+        for (int j = 0; j < 9; j++) w[j] = reinterpret_cast<const v4*>(lds[wave])[j * 64 + lane];
+    }
+    v4* o = reinterpret_cast<v4*>(out + c0 * 576);
+#pragma unroll
+    for (int j = 0; j < 9; j++) __builtin_nontemporal_store(w[j], o + j * 64 + lane);
+}
+template <int WIDE_LD>
+static int run_wide(const char* name, const float* a, float* b, long long nchunks, int rounds) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const unsigned grid = (unsigned)((nchunks + 15) / 16);
+    std::vector<float> t;
+    for (int r = 0; r < rounds + 1; r++) {
+        CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; i++) hipLaunchKernelGGL(kwide<WIDE_LD>, dim3(grid), dim3(256), 0, 0, a, b, nchunks);
+        CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r) t.push_back(ms / 5);
+    }
+    std::sort(t.begin(), t.end());
+    printf("%-40s: %.3f ms  %.3f TB/s\n", name, t[t.size() / 2], 2.0 * nchunks * 2304 / t[t.size() / 2] / 1e9);
+    fflush(stdout);
+    return 0;
+}
 static unsigned g_base = 0;
-template <int MODE, int PF>
+template <int MODE, int PF, int IO = 0>
 static int run(const char* name, const float* a, float* b, long long nchunks, int wg_per_cu, unsigned lds, int rounds, int sync_every = 8) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     unsigned grid; int iters;
@@ -93,7 +139,7 @@ static int run(const char* name, const float* a, float* b, long long nchunks, in
     for (int r = 0; r < rounds + 1; r++) {
         CHECK(hipEventRecord(e0, 0));
         for (int i = 0; i < 5; i++) {
-            hipLaunchKernelGGL((kstream<MODE, PF>), dim3(grid), dim3(256), lds, 0, a, b, nchunks, iters, sync_every, g_base);
+            hipLaunchKernelGGL((kstream<MODE, PF, IO>), dim3(grid), dim3(256), lds, 0, a, b, nchunks, iters, sync_every, g_base);
             if (MODE == LOCK) g_base += (unsigned)((iters - 1) / sync_every) * grid;  // arrivals this launch adds (iters not a multiple of PF+1 aside)
         }
         CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
@@ -102,7 +148,7 @@ static int run(const char* name, const float* a, float* b, long long nchunks, in
     }
     std::sort(t.begin(), t.end());
     printf("%-22s PF=%d  %d WG/CU (LDS %6u): %.3f ms  %.3f TB/s\n", name, PF, wg_per_cu, lds, t[t.size() / 2],
-           2.0 * nchunks * 2304 / t[t.size() / 2] / 1e9);
+           (IO ? 1.0 : 2.0) * nchunks * 2304 / t[t.size() / 2] / 1e9);
     fflush(stdout);
     return 0;
 }
@@ -116,6 +162,16 @@ int main(int argc, char** argv) {
     const struct { int wg; unsigned lds; } caps[] = {{4, 36u << 10}, {6, 26u << 10}, {3, 53u << 10}, {2, 80u << 10}};
     if (argc > 2)  // a soft grid-wide rendezvous every k steps: 0.3-3 TB/s, the rendezvous itself is what one measures
         for (int k : {1, 2, 4, 8, 32}) run<LOCK, 0>("long/sweep lockstep", a, b, nchunks, 4, 36u << 10, rounds, k);
+    run_wide<0>("4 chunks/wave, dword loads, float4 stores", a, b, nchunks, rounds);
+    run_wide<1>("4 chunks/wave, float4 loads and stores", a, b, nchunks, rounds);
+    run<SHORT, 0>("short", a, b, nchunks, 4, 36u << 10, rounds);
+    run<SHORT, 0, 1>("short read-only", a, b, nchunks, 4, 36u << 10, rounds);
+    run<SWEEP, 0, 1>("long/sweep read-only", a, b, nchunks, 4, 36u << 10, rounds);
+    run<SWEEP, 3, 1>("long/sweep read-only", a, b, nchunks, 4, 36u << 10, rounds);
+    run<SHORT, 0, 2>("short write-only", a, b, nchunks, 4, 36u << 10, rounds);
+    run<SWEEP, 0, 2>("long/sweep write-only", a, b, nchunks, 4, 36u << 10, rounds);
+    run<ROT, 0>("long/sweep rotated", a, b, nchunks, 4, 36u << 10, rounds);
+    run<ROT, 1>("long/sweep rotated", a, b, nchunks, 4, 36u << 10, rounds);
     for (int it : {2, 4, 8, 16, 64}) run<SWEEP, 0>("sweep, iters per wave:", a, b, nchunks, -it, 36u << 10, rounds);
     for (int it : {2, 8, 64}) run<OWN, 0>("own, iters per wave:", a, b, nchunks, -it, 36u << 10, rounds);
     for (int wg : {4, 6, 8}) { run<SPLIT, 0>("long/split", a, b, nchunks, wg, wg == 4 ? 36u << 10 : wg == 6 ? 26u << 10 : 0, rounds); run<SPLIT, 1>("long/split", a, b, nchunks, wg, wg == 4 ? 36u << 10 : wg == 6 ? 26u << 10 : 0, rounds); run<SPLIT, 3>("long/split", a, b, nchunks, wg, wg == 4 ? 36u << 10 : wg == 6 ? 26u << 10 : 0, rounds); }
