@@ -18,14 +18,13 @@ namespace lbm {
 // Algorithmic HBM bytes per cell-update: 36 read + 36 written (latticeboltzmann.py:176).
 // ---------------------------------------------------------------------------------------------
 template <int XMODE, typename T>
-__global__ __launch_bounds__(256) void step_kernel(const T* __restrict__ gin, T* __restrict__ gout,
+__global__ __launch_bounds__(64) void step_kernel(const T* __restrict__ gin, T* __restrict__ gout,
                                                    const uint64_t* __restrict__ mask, Geom geo,
                                                    int row0, int nrows, FastDiv by_mb) {
     const unsigned nwg = gridDim.x;
     const unsigned wg = xcd_remap(blockIdx.x, nwg);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const unsigned tile = wg * 4 + wave;  // the launcher keeps nrows * Mb below 2^31
+    const int lane = threadIdx.x;
+    const unsigned tile = wg;  // one wave per workgroup, one tile per wave (launch_step_t); nrows * Mb < 2^31
     if (tile >= (unsigned)nrows * (unsigned)geo.Mb) return;
     int yr, xb;
     fastdivmod(tile, by_mb, yr, xb);
@@ -279,39 +278,42 @@ __global__ __launch_bounds__(256) void init_discs_kernel(uint64_t* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 static inline unsigned tiles_to_wgs(long long tiles) { return (unsigned)((tiles + 3) / 4); }
 
-// Resident workgroups per CU of step_kernel.  The kernel needs 13 VGPRs and no LDS, so a CU would
-// take 8 workgroups (32 waves, 74 KB of loads in flight); the memory system delivers most with
-// about half of that in flight (tools/kbench.hip, 16384^2 fp32: 8 WG/CU 5.98 TB/s, 6: 6.06,
+// Resident waves per CU of step_kernel.  The kernel needs few VGPRs and no LDS, so a CU would
+// take 32 waves (74 KB of loads in flight); the memory system delivers most with about half of
+// that in flight (tools/kbench.hip, 16384^2 fp32, four-wave workgroups: 8 WG/CU 5.98 TB/s, 6: 6.06,
 // 5: 6.18, 4: 6.19, 3: 4.83; a pure copy in the kernel's own access shape 6.03 -> 6.30, which is what
 // a float4 streaming copy reaches).  The cap is imposed the portable way: an unused dynamic-LDS
-// request per workgroup (160 KB / 36 KB -> 4 resident workgroups, 16 KB left for other kernels).
+// request per workgroup.  Workgroups are ONE wave: a four-wave workgroup holds its LDS, i.e. its
+// place under the cap, until its last wave has finished, so fewer than sixteen waves are at work on
+// average; with single-wave workgroups the cap is exact (same-box: 87.1 -> 87.8 GLUPS; 17 per CU at
+// 9 KB each and 16 at 10 KB give the same, 13 at 12 KB 85.0, uncapped 80.5).
 // fp16 storage has half the bytes per wave in flight and twice the arithmetic per byte: it wants
-// all 8 workgroups (150 GLUPS uncapped, 129 at 5, 114 at 4).
+// all 32 waves (uncapped 174.5 GLUPS with single-wave workgroups, 173.1 with four-wave ones).
 static unsigned step_lds_cap(bool half) {
     static const int env = [] {
         const char* e = getenv("LBM_T1_LDS_CAP");  // development override, bytes per workgroup
         return e ? atoi(e) : -1;
     }();
     if (env >= 0) return (unsigned)env;
-    return half ? 0u : 36u << 10;
+    return half ? 0u : 9u << 10;
 }
 
 template <typename T>
 static hipError_t launch_step_t(const T* gin, T* gout, const uint64_t* mask, const Geom& geo,
                                 int xmode, int row0, int nrows, hipStream_t st) {
     if ((long long)nrows * geo.Mb >= (1ll << 31) - 4) return hipErrorInvalidValue;  // 1.3e11 cells
-    const unsigned nwg = tiles_to_wgs((long long)nrows * geo.Mb);
+    const unsigned nwg = (unsigned)((long long)nrows * geo.Mb);  // one single-wave workgroup per tile
     if (nwg == 0) return hipSuccess;
     const unsigned lds = step_lds_cap(sizeof(T) == 2);
     const FastDiv by_mb = make_fastdiv(geo.Mb);
     if (xmode == XMODE_PERIODIC)
-        hipLaunchKernelGGL((step_kernel<XMODE_PERIODIC, T>), dim3(nwg), dim3(256), lds, st, gin, gout,
+        hipLaunchKernelGGL((step_kernel<XMODE_PERIODIC, T>), dim3(nwg), dim3(64), lds, st, gin, gout,
                            mask, geo, row0, nrows, by_mb);
     else if (xmode == XMODE_CUDA)
-        hipLaunchKernelGGL((step_kernel<XMODE_CUDA, T>), dim3(nwg), dim3(256), 0, st, gin, gout,
+        hipLaunchKernelGGL((step_kernel<XMODE_CUDA, T>), dim3(nwg), dim3(64), 0, st, gin, gout,
                            mask, geo, row0, nrows, by_mb);
     else
-        hipLaunchKernelGGL((step_kernel<XMODE_REFERENCE, T>), dim3(nwg), dim3(256), lds, st, gin, gout,
+        hipLaunchKernelGGL((step_kernel<XMODE_REFERENCE, T>), dim3(nwg), dim3(64), lds, st, gin, gout,
                            mask, geo, row0, nrows, by_mb);
     return hipGetLastError();
 }
