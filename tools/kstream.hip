@@ -17,7 +17,7 @@
 enum { SHORT = 0, SWEEP = 1, OWN = 2, WG = 3, SPLIT = 4, LOCK = 5, ROT = 6 };  // ROT: sweep, but which wave takes which chunk of the span changes every step  // LOCK: sweep with a soft (bounded-spin) grid-wide rendezvous every SYNC_EVERY steps  // SPLIT: sweep, odd waves only load, even waves only store
 
 __device__ unsigned g_arrived;
-template <int MODE, int PF, int IO = 0>  // IO: 0 copy, 1 read only, 2 write only
+template <int MODE, int PF, int IO = 0, int EXTRA = 0>  // IO: 0 copy, 1 read only, 2 write only; EXTRA: per-step extras (1 s_sleep, 2 L1 invalidate, 3 rotating priority, 4 wait for the stores)
 __global__ __launch_bounds__(256) void kstream(const float* __restrict__ in, float* __restrict__ out,
                                                long long nchunks, int iters, int sync_every, unsigned arrive_base) {
     const int lane = threadIdx.x & 63;
@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256) void kstream(const float* __restrict__ in, flo
             }
             __syncthreads();
         }
+        if (EXTRA == 1) __builtin_amdgcn_s_sleep(2);
+        if (EXTRA == 2) asm volatile("buffer_inv sc1");
+        if (EXTRA == 3) { if (it & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+        if (EXTRA == 4) __builtin_amdgcn_s_waitcnt(0);
 #pragma unroll
         for (int u = 0; u <= PF; u++) {
             if (it + u < iters) {
@@ -127,7 +131,7 @@ static int run_wide(const char* name, const float* a, float* b, long long nchunk
     return 0;
 }
 static unsigned g_base = 0;
-template <int MODE, int PF, int IO = 0>
+template <int MODE, int PF, int IO = 0, int EXTRA = 0>
 static int run(const char* name, const float* a, float* b, long long nchunks, int wg_per_cu, unsigned lds, int rounds, int sync_every = 8) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     unsigned grid; int iters;
@@ -139,7 +143,7 @@ static int run(const char* name, const float* a, float* b, long long nchunks, in
     for (int r = 0; r < rounds + 1; r++) {
         CHECK(hipEventRecord(e0, 0));
         for (int i = 0; i < 5; i++) {
-            hipLaunchKernelGGL((kstream<MODE, PF, IO>), dim3(grid), dim3(256), lds, 0, a, b, nchunks, iters, sync_every, g_base);
+            hipLaunchKernelGGL((kstream<MODE, PF, IO, EXTRA>), dim3(grid), dim3(256), lds, 0, a, b, nchunks, iters, sync_every, g_base);
             if (MODE == LOCK) g_base += (unsigned)((iters - 1) / sync_every) * grid;  // arrivals this launch adds (iters not a multiple of PF+1 aside)
         }
         CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
@@ -162,6 +166,11 @@ int main(int argc, char** argv) {
     const struct { int wg; unsigned lds; } caps[] = {{4, 36u << 10}, {6, 26u << 10}, {3, 53u << 10}, {2, 80u << 10}};
     if (argc > 2)  // a soft grid-wide rendezvous every k steps: 0.3-3 TB/s, the rendezvous itself is what one measures
         for (int k : {1, 2, 4, 8, 32}) run<LOCK, 0>("long/sweep lockstep", a, b, nchunks, 4, 36u << 10, rounds, k);
+    run<SWEEP, 0, 0, 0>("long/sweep", a, b, nchunks, 4, 36u << 10, rounds);
+    run<SWEEP, 0, 0, 1>("long/sweep + s_sleep", a, b, nchunks, 4, 36u << 10, rounds);
+    run<SWEEP, 0, 0, 2>("long/sweep + wbinvl1", a, b, nchunks, 4, 36u << 10, rounds);
+    run<SWEEP, 0, 0, 3>("long/sweep + setprio", a, b, nchunks, 4, 36u << 10, rounds);
+    run<SWEEP, 0, 0, 4>("long/sweep + waitcnt0", a, b, nchunks, 4, 36u << 10, rounds);
     run_wide<0>("4 chunks/wave, dword loads, float4 stores", a, b, nchunks, rounds);
     run_wide<1>("4 chunks/wave, float4 loads and stores", a, b, nchunks, rounds);
     run<SHORT, 0>("short", a, b, nchunks, 4, 36u << 10, rounds);
