@@ -166,6 +166,13 @@ int main(int argc, char** argv) {
     const struct { int wg; unsigned lds; } caps[] = {{4, 36u << 10}, {6, 26u << 10}, {3, 53u << 10}, {2, 80u << 10}};
     if (argc > 2)  // a soft grid-wide rendezvous every k steps: 0.3-3 TB/s, the rendezvous itself is what one measures
         for (int k : {1, 2, 4, 8, 32}) run<LOCK, 0>("long/sweep lockstep", a, b, nchunks, 4, 36u << 10, rounds, k);
+    for (int wg : {1, 2, 3}) {
+        const unsigned l = wg == 1 ? 100u << 10 : wg == 2 ? 60u << 10 : 50u << 10;
+        run<SWEEP, 0>("long/sweep", a, b, nchunks, wg, l, rounds);
+        run<SWEEP, 1>("long/sweep", a, b, nchunks, wg, l, rounds);
+        run<SWEEP, 3>("long/sweep", a, b, nchunks, wg, l, rounds);
+        run<OWN, 1>("long/own", a, b, nchunks, wg, l, rounds);
+    }
     run<SWEEP, 0, 0, 0>("long/sweep", a, b, nchunks, 4, 36u << 10, rounds);
     run<SWEEP, 0, 0, 1>("long/sweep + s_sleep", a, b, nchunks, 4, 36u << 10, rounds);
     run<SWEEP, 0, 0, 2>("long/sweep + wbinvl1", a, b, nchunks, 4, 36u << 10, rounds);
