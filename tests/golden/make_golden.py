@@ -11,6 +11,10 @@
                    none of it).  The oracle (numpy and C), and through it the HIP path, are pinned
                    to these.  The periodic scene replaces the reference's stream() by np.roll (no
                    reference counterpart); everything else in it is the reference's text too.
+  sha_cyl400x800_reference.npz
+                   sha256 of cells / rho / u after 1, 100, 1000 steps of the same reference lines
+                   on BASELINE config 1's own scene (400 x 800 cylinder, latticeboltzmann.jl:25-32):
+                   digests only, so the fixture stays a few hundred bytes.
 """
 import hashlib
 import os
@@ -64,7 +68,34 @@ def fields(tag, N, M, blocked, cells, omega, u_amb, boundary, checkpoints):
     print(tag, "done")
 
 
+def sha_only(tag, N, M, blocked, omega, u_amb, checkpoints):
+    """BASELINE config 1 at its own size: only sha256 digests of cells / rho / u (a few hundred
+    bytes) after the given step counts of the reference's own lines, from its own initial state."""
+    ref = ref_extract.ReferenceNumpyPath(blocked, {"OMEGA": omega, "u_ambient": u_amb})
+    out = {"shape": np.array([N, M]), "omega": np.array(omega, np.float64),
+           "surroundings": ref.surroundings, "blocked_sha": _sha(np.packbits(blocked)),
+           "source": np.array("reference text via tests/golden/ref_extract.py")}
+    done = 0
+    for c in checkpoints:
+        cells = ref.step(c - done)
+        done = c
+        u, p = ref.moments()
+        out[f"cells_sha_{c}"] = _sha(cells)
+        out[f"rho_sha_{c}"] = _sha(p)
+        out[f"u_sha_{c}"] = _sha(u)
+        print(tag, c, flush=True)
+    np.savez_compressed(os.path.join(HERE, f"sha_{tag}.npz"), **out)
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "cyl400x800":  # only the (2 min) full-size cylinder digest
+        sha_only("cyl400x800_reference", 400, 800, onp.blocked_cylinder(400, 800), onp.OMEGA, [0, 0.1],
+                 (1, 100, 1000))
+        return
     masks()
     # 64 x 128 cylinder-like scene, reference boundaries, reference parameters
     N, M = 64, 128
@@ -87,6 +118,9 @@ def main():
     b = rng.random((N, M)) < 0.05
     fields("rand48x80_periodic", N, M, b, onp.perturbed_cells(N, M, seed=0, amp=0.01), 0.1, [0, 0.1],
            "periodic", (1, 10, 100))
+    # BASELINE config 1 itself: the 400 x 800 cylinder of latticeboltzmann.jl:25-32, digests only
+    sha_only("cyl400x800_reference", 400, 800, onp.blocked_cylinder(400, 800), onp.OMEGA, [0, 0.1],
+             (1, 100, 1000))
 
 
 if __name__ == "__main__":

@@ -136,6 +136,40 @@ def test_golden_fields(tag, boundary):
             assert np.array_equal(sha, z[f"cells_sha_{c}"])
 
 
+def cyl400x800_digests():
+    """sha256 digests of BASELINE config 1's own scene (400 x 800 cylinder, latticeboltzmann.jl:25-32)
+    after 1 / 100 / 1000 steps of the reference's own numpy lines (make_golden.py `sha_only`)."""
+    z = np.load(os.path.join(GOLD, "sha_cyl400x800_reference.npz"))
+    assert str(z["source"]).startswith("reference text") and tuple(z["shape"]) == (400, 800)
+    assert float(z["omega"]) == onp.OMEGA and np.array_equal(z["surroundings"], onp.ambient())
+    return z
+
+
+def sha_of(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def test_config1_cylinder_digests():
+    """BASELINE config 1 pinned directly: the C restatement on the 400 x 800 cylinder for 1000 steps
+    against digests of the reference's own lines (the numpy restatement runs the first 100)."""
+    z = cyl400x800_digests()
+    blocked = onp.blocked_cylinder(400, 800)
+    assert np.array_equal(sha_of(np.packbits(blocked)), z["blocked_sha"])
+    surr = onp.ambient()
+    c = onp.initial_cells(blocked, surr)
+    n = c.copy()
+    done = 0
+    for k in (1, 100, 1000):
+        oc.run(c, blocked, k - done, onp.OMEGA, surr, "reference")
+        if k <= 100:
+            onp.run(n, blocked, k - done, onp.OMEGA, surr, "reference")
+            assert np.array_equal(n, c)
+        done = k
+        u, p = oc.moments(c)
+        assert np.array_equal(sha_of(c), z[f"cells_sha_{k}"])
+        assert np.array_equal(sha_of(p), z[f"rho_sha_{k}"]) and np.array_equal(sha_of(u), z[f"u_sha_{k}"])
+
+
 def test_float64_omega_is_what_the_fixtures_pin():
     """latticeboltzmann.py:98 builds omega as float64; a float32 omega (round 1's restatement)
     must NOT reproduce the fixtures, or they would not pin that line."""

@@ -62,17 +62,37 @@ def test_small_random_scene(boundary, shape):
     s.close()
 
 
-def test_cylinder_1000_steps():
-    """BASELINE config 1 scene: 400x800 cylinder, OMEGA=1e-14, rho=100, u=[0,0.1], 1000 steps."""
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+@pytest.mark.parametrize("tb_max_depth", [1, 6])
+def test_cylinder_1000_steps(tb_max_depth):
+    """BASELINE config 1 scene: 400x800 cylinder, OMEGA=1e-14, rho=100, u=[0,0.1], 1000 steps, with
+    the plain kernel (launch depth 1) and the LDS kernel (depth 6).  Compared with the oracle bit for
+    bit AND with tests/golden/sha_cyl400x800_reference.npz: digests of cells / rho / u after 1, 100
+    and 1000 steps of the reference's OWN numpy lines on this scene (tests/golden/make_golden.py)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sha_cyl400x800_reference.npz"))
+    assert str(z["source"]).startswith("reference text")
     blocked = onp.blocked_cylinder(400, 800)
+    assert np.array_equal(_sha(np.packbits(blocked)), z["blocked_sha"])
     surr = onp.ambient()
+    assert np.array_equal(surr, z["surroundings"]) and float(z["omega"]) == onp.OMEGA
     cells = onp.initial_cells(blocked, surr)
     s = _solver(400, 800, blocked, cells)
+    s.set_tuning(tb_max_depth, 0)
     ref = cells.copy()
+    done = 0
     for chunk in (1, 99, 900):
         s.fused_collide_stream(chunk)
         oc.run(ref, blocked, chunk, onp.OMEGA, surr)
+        done += chunk
         _compare(s, ref)
+        u, rho = s.read_moments()
+        assert np.array_equal(_sha(s.read_cells()), z[f"cells_sha_{done}"])
+        assert np.array_equal(_sha(rho), z[f"rho_sha_{done}"]) and np.array_equal(_sha(u), z[f"u_sha_{done}"])
     s.close()
 
 

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -130,6 +131,62 @@ static int run_wide(const char* name, const float* a, float* b, long long nchunk
     fflush(stdout);
     return 0;
 }
+// DYN: persistent waves that take their chunks from a queue (one counter per XCD band, G chunks per
+// grab) instead of a fixed assignment: chunk order = the order in which waves become free, which is
+// what the hardware dispatcher gives one-chunk waves.  If the lifetime effect were waves drifting
+// apart (a front spread over ever more DRAM pages), this would run like `short`.
+__device__ unsigned g_next[8 * 32];  // one counter per XCD, 128 bytes apart
+template <int G>
+__global__ __launch_bounds__(256) void kdyn(const float* __restrict__ in, float* __restrict__ out, long long nchunks) {
+    const int lane = threadIdx.x & 63;
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned band = (unsigned)(nchunks / 8), lo = xcd * band;  // nchunks is a multiple of 8 here
+    auto grab = [&]() -> unsigned {
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(&g_next[xcd * 32], (unsigned)G);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    unsigned cur = grab();
+    while (cur < band) {  // the counter only grows: every wave gets here with cur >= band in the end
+        const unsigned nxt = grab();
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const unsigned c = cur + g;
+            if (c < band) {
+                const float* p = in + (long long)(lo + c) * 576 + lane;
+                float v[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = __builtin_nontemporal_load(p + 64 * k);
+                float* o = out + (long long)(lo + c) * 576 + lane;
+#pragma unroll
+                for (int k = 0; k < 9; k++) __builtin_nontemporal_store(v[k], o + 64 * k);
+            }
+        }
+        cur = nxt;
+    }
+}
+template <int G>
+static int run_dyn(const char* name, const float* a, float* b, long long nchunks, int wg_per_cu, unsigned lds, int rounds) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    void* cnt; CHECK(hipGetSymbolAddress(&cnt, HIP_SYMBOL(g_next)));
+    const unsigned grid = 256u * wg_per_cu;
+    std::vector<float> t;
+    for (int r = 0; r < rounds + 1; r++) {
+        CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; i++) {
+            CHECK(hipMemsetAsync(cnt, 0, sizeof(unsigned) * 8 * 32, 0));
+            hipLaunchKernelGGL(kdyn<G>, dim3(grid), dim3(256), lds, 0, a, b, nchunks);
+        }
+        CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r) t.push_back(ms / 5);
+    }
+    std::sort(t.begin(), t.end());
+    printf("%-22s G=%d  %d WG/CU (LDS %6u): %.3f ms  %.3f TB/s\n", name, G, wg_per_cu, lds, t[t.size() / 2],
+           2.0 * nchunks * 2304 / t[t.size() / 2] / 1e9);
+    fflush(stdout);
+    return 0;
+}
 static unsigned g_base = 0;
 template <int MODE, int PF, int IO = 0, int EXTRA = 0>
 static int run(const char* name, const float* a, float* b, long long nchunks, int wg_per_cu, unsigned lds, int rounds, int sync_every = 8) {
@@ -164,6 +221,23 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&a, nchunks * 2304)); CHECK(hipMalloc(&b, nchunks * 2304));
     CHECK(hipMemset(a, 0, nchunks * 2304));
     const struct { int wg; unsigned lds; } caps[] = {{4, 36u << 10}, {6, 26u << 10}, {3, 53u << 10}, {2, 80u << 10}};
+    if (argc > 2 && !strcmp(argv[2], "pmc")) {  // the two ends of the lifetime effect only (for rocprofv3 --pmc passes)
+        run<SHORT, 0>("short", a, b, nchunks, 4, 36u << 10, rounds);
+        run<SWEEP, 0>("long/sweep", a, b, nchunks, 4, 36u << 10, rounds);
+        return 0;
+    }
+    if (argc > 2 && !strcmp(argv[2], "dyn")) {  // queue-fed persistent waves against both ends
+        run<SHORT, 0>("short", a, b, nchunks, 4, 36u << 10, rounds);
+        run<SWEEP, 0>("long/sweep", a, b, nchunks, 4, 36u << 10, rounds);
+        run_dyn<1>("long/queue", a, b, nchunks, 4, 36u << 10, rounds);
+        run_dyn<2>("long/queue", a, b, nchunks, 4, 36u << 10, rounds);
+        run_dyn<4>("long/queue", a, b, nchunks, 4, 36u << 10, rounds);
+        run_dyn<16>("long/queue", a, b, nchunks, 4, 36u << 10, rounds);
+        run_dyn<1>("long/queue", a, b, nchunks, 6, 26u << 10, rounds);
+        run_dyn<4>("long/queue", a, b, nchunks, 6, 26u << 10, rounds);
+        run<SHORT, 0>("short", a, b, nchunks, 4, 36u << 10, rounds);
+        return 0;
+    }
     if (argc > 2)  // a soft grid-wide rendezvous every k steps: 0.3-3 TB/s, the rendezvous itself is what one measures
         for (int k : {1, 2, 4, 8, 32}) run<LOCK, 0>("long/sweep lockstep", a, b, nchunks, 4, 36u << 10, rounds, k);
     for (int wg : {1, 2, 3}) {

@@ -1,0 +1,248 @@
+// Development micro-benchmark, round 3: the T = 1 kernel in the PRODUCT's launch
+// shape (single-wave workgroups, residency capped by an unused 9 KB dynamic-LDS request, XCD bands,
+// non-temporal loads and stores, tiny-omega common path), timed interleaved in one process with
+//   panel   the same update on a PANEL layout  field[panel][row][xb in panel][slot][lane]  (P blocks
+//           per panel, tiles walked panel by panel): the memory shape of a narrow grid for a square one
+//   copies  yardsticks without arithmetic: two buffers against IN PLACE (destination = source), for a
+//           whole chunk and for the three-row shape of the pull (the access pattern an AA-pattern /
+//           esoteric-pull kernel would have), aligned and lane-shifted
+// Every real variant is checked against `base` by an order-independent checksum of the result bits.
+// Not part of the product; build: make -C tools kt1.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../latticeboltzmann_amd/csrc/lbm_device.h"
+
+using namespace lbm;
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Lay {
+    int N, Mb, P;        // rows, blocks per row, blocks per panel (P == Mb: plain row-major)
+    long long panelStride;  // elements per panel = N * S * CHUNK
+    int S;               // allocated blocks per panel row (S > P: padded row stride)
+};
+// element offset of chunk (y, xb)
+__device__ __forceinline__ long long chunk_off(const Lay& L, int y, int xb) {
+    const int pn = xb / L.P, xi = xb - pn * L.P;  // wave-uniform
+    return (long long)pn * L.panelStride + ((long long)y * L.S + xi) * CHUNK;
+}
+
+enum { K_STEP = 0, K_COPY = 1, K_COPY3 = 2, K_COPY3S = 3, K_STEP2 = 4 };
+// INPLACE: the destination is the source location(s); for K_COPY3* that means the three 768-byte
+// pieces go back where they came from (rows y-1, y, y+1), as an AA-pattern odd step would write.
+template <int KIND, bool INPLACE>
+__global__ __launch_bounds__(64) void kt1(const float* __restrict__ gin, float* __restrict__ gout, Lay L,
+                                          FastDiv by_p, Geom geo) {
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x;
+    // tile -> (panel, y, xi): panel-major, row-major inside a panel
+    int row_in_all, xi;
+    fastdivmod(tile, by_p, row_in_all, xi);  // row_in_all = panel * N + y
+    const int pn = row_in_all / L.N;          // scalar division, wave-uniform (fine for a benchmark)
+    const int y = row_in_all - pn * L.N;
+    if (KIND == K_STEP2) {
+        // the product kernel's addressing (lbm_device.h pull<>): wave-uniform row bases, 32-bit lane
+        // offsets inside the panel row, all nine loads issued at once; a tile at a panel seam fetches
+        // the one lane that falls into the neighbouring panel by three single-lane loads (rare,
+        // wave-uniform branch).  P == Mb: one panel, the seam is the periodic wrap.
+        const int np = L.Mb / L.P;
+        const int yu = y == 0 ? L.N - 1 : y - 1, yd = y == L.N - 1 ? 0 : y + 1;
+        const float* pan = gin + (long long)pn * L.panelStride;
+        const float* rp[3] = {pan + (long long)yd * L.S * CHUNK, pan + (long long)y * L.S * CHUNK,
+                              pan + (long long)yu * L.S * CHUNK};
+        const bool seam_m = xi == L.P - 1, seam_p = xi == 0;  // wave-uniform
+        const unsigned off0 = (unsigned)(xi * CHUNK + lane);
+        const unsigned offm = lane == 63 ? (seam_m ? off0 : (unsigned)((xi + 1) * CHUNK)) : off0 + 1;
+        const unsigned offp = lane == 0 ? (seam_p ? off0 : (unsigned)((xi - 1) * CHUNK + 63)) : off0 - 1;
+        float v[Q];
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
+            const unsigned off = dx == 0 ? off0 : (dx == 1 ? offp : offm);
+            v[k] = __builtin_nontemporal_load(reinterpret_cast<const float*>(
+                reinterpret_cast<const char*>(rp[dy + 1] + sl) + (size_t)(off * 4u)));
+        }
+        if (seam_m | seam_p) {
+            const int pnm = pn + 1 == np ? 0 : pn + 1, pnp = pn == 0 ? np - 1 : pn - 1;
+            const long long rowo[3] = {(long long)yd * L.S * CHUNK, (long long)y * L.S * CHUNK, (long long)yu * L.S * CHUNK};
+#pragma unroll
+            for (int k = 0; k < Q; k++) {
+                const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
+                if (dx == -1 && seam_m && lane == 63) v[k] = gin[(long long)pnm * L.panelStride + rowo[dy + 1] + sl];
+                if (dx == 1 && seam_p && lane == 0) v[k] = gin[(long long)pnp * L.panelStride + rowo[dy + 1] + (long long)(L.P - 1) * CHUNK + sl + 63];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < Q; k++) asm("" : "+v"(v[k]));
+        collide_to(v, false, 0ull, omega_of(geo), [&](const float* out) {
+            float* o = gout + (long long)pn * L.panelStride + ((long long)y * L.S + xi) * CHUNK + lane;
+#pragma unroll
+            for (int k = 0; k < Q; k++) __builtin_nontemporal_store(out[k], o + slot_of(k) * LANES);
+        });
+        return;
+    }
+    const int xb = pn * L.P + xi;
+    const int yu = y == 0 ? L.N - 1 : y - 1, yd = y == L.N - 1 ? 0 : y + 1;
+    const int xbm = xb + 1 == L.Mb ? 0 : xb + 1, xbp = xb == 0 ? L.Mb - 1 : xb - 1;
+    // per source row: own block and the two neighbour blocks (a neighbour may be in another panel)
+    const long long o0[3] = {chunk_off(L, yd, xb), chunk_off(L, y, xb), chunk_off(L, yu, xb)};    // index dy+1
+    const long long om[3] = {chunk_off(L, yd, xbm), chunk_off(L, y, xbm), chunk_off(L, yu, xbm)};
+    const long long op[3] = {chunk_off(L, yd, xbp), chunk_off(L, y, xbp), chunk_off(L, yu, xbp)};
+    float a[Q];
+    if (KIND == K_COPY) {
+        const float* p = gin + o0[1] + lane;
+#pragma unroll
+        for (int k = 0; k < Q; k++) a[k] = __builtin_nontemporal_load(p + 64 * k) + 1.0f;  // (a changed value: `*p = *p` would be deleted)
+        float* o = (INPLACE ? const_cast<float*>(gin) : gout) + o0[1] + lane;
+#pragma unroll
+        for (int k = 0; k < Q; k++) __builtin_nontemporal_store(a[k], o + 64 * k);
+        return;
+    }
+    const float* src[Q];
+#pragma unroll
+    for (int k = 0; k < Q; k++) {
+        const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
+        long long off;
+        if (KIND == K_COPY3 || dx == 0) off = o0[dy + 1] + lane;
+        else if (dx == -1) off = lane == 63 ? om[dy + 1] : o0[dy + 1] + lane + 1;       // source x+1
+        else off = lane == 0 ? op[dy + 1] + 63 : o0[dy + 1] + lane - 1;                  // source x-1
+        src[k] = gin + off + sl;
+        a[k] = __builtin_nontemporal_load(src[k]);
+    }
+    if (KIND == K_STEP) {
+#pragma unroll
+        for (int k = 0; k < Q; k++) asm("" : "+v"(a[k]));
+        collide_to(a, false, 0ull, omega_of(geo), [&](const float* out) {
+            float* o = gout + o0[1] + lane;
+#pragma unroll
+            for (int k = 0; k < Q; k++) __builtin_nontemporal_store(out[k], o + slot_of(k) * LANES);
+        });
+        return;
+    }
+    if (INPLACE) {
+#pragma unroll
+        for (int k = 0; k < Q; k++) __builtin_nontemporal_store(a[k] + 1.0f, const_cast<float*>(src[k]));
+    } else {
+        float* o = gout + o0[1] + lane;
+#pragma unroll
+        for (int k = 0; k < Q; k++) __builtin_nontemporal_store(a[k], o + slot_of(k) * LANES);
+    }
+}
+
+// value of (y, x, slot), independent of the layout
+__global__ void initk(float* f, Lay L) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over N * Mb * 576 logical elements
+    const long long n = (long long)L.N * L.Mb * CHUNK;
+    if (i >= n) return;
+    const int lane = (int)(i & 63), slot = (int)((i >> 6) % 9);
+    const long long c = i / CHUNK;
+    const int xb = (int)(c % L.Mb), y = (int)(c / L.Mb);
+    const float base[9] = {2.03f, 10.9f, 3.69f, 8.11f, 43.8f, 14.8f, 2.03f, 10.9f, 3.69f};
+    unsigned h = (unsigned)(i * 2654435761u); h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    f[chunk_off(L, y, xb) + slot * 64 + lane] = base[slot] * (1.0f + 0.01f * ((h & 0xffff) / 32768.0f - 1.0f));
+}
+// order-independent checksum: sum over logical elements of bits * (position hash)
+__global__ void sumk(const float* f, Lay L, unsigned long long* acc) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)L.N * L.Mb * CHUNK;
+    unsigned long long v = 0;
+    if (i < n) {
+        const int lane = (int)(i & 63), slot = (int)((i >> 6) % 9);
+        const long long c = i / CHUNK;
+        const int xb = (int)(c % L.Mb), y = (int)(c / L.Mb);
+        v = (unsigned long long)__float_as_uint(f[chunk_off(L, y, xb) + slot * 64 + lane]) * (2ull * (unsigned long long)i + 1);
+    }
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, v);
+}
+
+typedef void (*Kfn)(const float*, float*, Lay, FastDiv, Geom);
+struct Var { const char* name; Kfn fn; int P; bool inplace; bool real; double bytes; int pad; };
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 16384, M = argc > 2 ? atoi(argv[2]) : 16384;
+    const int rounds = argc > 3 ? atoi(argv[3]) : 5, reps = 10;
+    const unsigned lds = argc > 4 ? (unsigned)atoi(argv[4]) : 9u << 10;
+    const int Mb = M / 64;
+    Geom geo{};
+    geo.N = N; geo.M = M; geo.Mb = Mb; geo.omega = 1e-14; geo.omega_f = 1e-14f; geo.omega_tiny = 1;
+    const size_t bytes = (size_t)N * Mb * CHUNK * 4 * 5 / 4;  // room for padded row strides
+    float *a, *b; unsigned long long* acc;
+    CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes)); CHECK(hipMalloc(&acc, 8));
+    const double step_bytes = 72.0 * N * M;
+    std::vector<Var> vars;
+    vars.push_back({"step row-major", kt1<K_STEP, false>, Mb, false, true, step_bytes});
+    for (int P : {8, 16, 23, 32, 64}) {
+        if (Mb % P && P != 23) continue;
+        if (P >= Mb) continue;
+        char* nm = new char[64]; snprintf(nm, 64, "step panels P=%d", P);
+        vars.push_back({nm, kt1<K_STEP, false>, P, false, true, step_bytes});
+    }
+    vars.push_back({"step2 row-major", kt1<K_STEP2, false>, Mb, false, true, step_bytes});
+    for (int P : {16, 23, 32, 64}) {
+        if (Mb % P || P >= Mb) continue;
+        char* nm = new char[64]; snprintf(nm, 64, "step2 panels P=%d", P);
+        vars.push_back({nm, kt1<K_STEP2, false>, P, false, true, step_bytes});
+    }
+    for (int pad : {1, 3, 8}) {
+        char* nm = new char[64]; snprintf(nm, 64, "step2 row-major pad=%d", pad);
+        vars.push_back({nm, kt1<K_STEP2, false>, Mb, false, true, step_bytes, pad});
+    }
+    if (Mb % 32 == 0 && Mb > 32) vars.push_back({"step2 panels P=32 pad=1", kt1<K_STEP2, false>, 32, false, true, step_bytes, 1});
+    vars.push_back({"copy chunk 2buf", kt1<K_COPY, false>, Mb, false, false, step_bytes});
+    vars.push_back({"copy chunk inplace", kt1<K_COPY, true>, Mb, true, false, step_bytes});
+    vars.push_back({"copy 3rows 2buf", kt1<K_COPY3, false>, Mb, false, false, step_bytes});
+    vars.push_back({"copy 3rows inplace", kt1<K_COPY3, true>, Mb, true, false, step_bytes});
+    vars.push_back({"copy 3rows shifted 2buf", kt1<K_COPY3S, false>, Mb, false, false, step_bytes});
+    vars.push_back({"copy 3rows shifted inplace", kt1<K_COPY3S, true>, Mb, true, false, step_bytes});
+    vars.push_back({"copy 3rows 2buf P=16", kt1<K_COPY3, false>, 16, false, false, step_bytes});
+    vars.push_back({"copy 3rows inplace P=16", kt1<K_COPY3, true>, 16, true, false, step_bytes});
+
+    auto lay_of = [&](int P, int pad) {
+        // a last panel narrower than P is not supported here: P = 23 pads Mb up in the benchmark only
+        Lay L{N, Mb, P, (long long)N * (P + pad) * CHUNK, P + pad};
+        return L;
+    };
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const unsigned ntiles = (unsigned)((long long)N * Mb);
+    unsigned long long sum0 = 0;
+    std::vector<std::vector<float>> ms(vars.size());
+    for (int r = 0; r < rounds + 1; r++) {
+        for (size_t v = 0; v < vars.size(); v++) {
+            const Var& V = vars[v];
+            if (Mb % V.P) continue;
+            const Lay L = lay_of(V.P, V.pad);
+            const FastDiv by_p = make_fastdiv(V.P);
+            if (V.real)  // the state in this variant's layout (garbage would leave the common path)
+                hipLaunchKernelGGL(initk, dim3((unsigned)(((long long)N * Mb * CHUNK + 255) / 256)), dim3(256), 0, 0, a, L);
+            if (r == 0 && V.real) {  // correctness: one update from the same logical state
+                hipLaunchKernelGGL(initk, dim3((unsigned)(((long long)N * Mb * CHUNK + 255) / 256)), dim3(256), 0, 0, a, L);
+                hipLaunchKernelGGL(V.fn, dim3(ntiles), dim3(64), lds, 0, (const float*)a, b, L, by_p, geo);
+                CHECK(hipMemset(acc, 0, 8));
+                hipLaunchKernelGGL(sumk, dim3((unsigned)(((long long)N * Mb * CHUNK + 255) / 256)), dim3(256), 0, 0, (const float*)b, L, acc);
+                unsigned long long s = 0; CHECK(hipMemcpy(&s, acc, 8, hipMemcpyDeviceToHost));
+                if (v == 0) sum0 = s;
+                printf("%-28s checksum %016llx %s\n", V.name, s, s == sum0 ? "ok" : "DIFFERS");
+            }
+            CHECK(hipEventRecord(e0, 0));
+            for (int i = 0; i < reps; i++) {
+                hipLaunchKernelGGL(V.fn, dim3(ntiles), dim3(64), lds, 0, (const float*)a, b, L, by_p, geo);
+                if (!V.inplace) std::swap(a, b);
+            }
+            CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+            float t; CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (r > 0) ms[v].push_back(t / reps);
+        }
+    }
+    for (size_t v = 0; v < vars.size(); v++) {
+        if (ms[v].empty()) continue;
+        std::sort(ms[v].begin(), ms[v].end());
+        const float med = ms[v][ms[v].size() / 2];
+        printf("%-28s median %.4f ms  min %.4f  %.3f TB/s  frac %.4f\n", vars[v].name, med, ms[v][0],
+               vars[v].bytes / med / 1e9, vars[v].bytes / med / 1e9 / 8.0);
+    }
+    return 0;
+}
