@@ -121,7 +121,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        import faulthandler
         import torch.distributed as dist
+        # A hang on the N > 1 path must end the run with a traceback and a non-zero status, not at
+        # the driver's limit with nothing written: every slab wait is a bounded host-side poll
+        # (SlabSolver.timeout_s -> SlabTimeout), and this is the backstop for everything else
+        # (collectives, process-group set-up).  Never a re-exec.
+        hang_s = float(os.environ.get("LBM_BENCH_HANG_S", "600"))
+        faulthandler.dump_traceback_later(hang_s, exit=True)
         # RCCL on a real node; LBM_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks
         # on one GPU (halos staged through the host), never for a reported number
         backend = os.environ.get("LBM_BENCH_BACKEND", "nccl")
@@ -212,6 +219,7 @@ def main():
     else:
         slab = SlabSolver(rows * world, cols, OMEGA, rank, world, boundary="periodic",
                           halo=args.halo, device=local_rank, dist=dist, tb_max_depth=args.depth)
+        slab.timeout_s = min(slab.timeout_s, hang_s / 2)
         slab.set_surroundings(surr)
         slab.init_device_scene(100.0, (0.0, 0.1), amp=0.01, seed=0)
         slab.step(args.warmup)
@@ -248,6 +256,7 @@ def main():
             try:
                 s4 = SlabSolver(rows * world, cols, OMEGA, rank, world, boundary="periodic",
                                 halo=args.halo, device=local_rank, dist=dist, tb_max_depth=d)
+                s4.timeout_s = min(s4.timeout_s, hang_s / 2)
                 s4.set_surroundings(surr)
                 s4.init_device_scene(100.0, (0.0, 0.1), amp=0.01, seed=0)
             except Exception as e:  # never let the extra line break the headline ...
@@ -315,6 +324,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

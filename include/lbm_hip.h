@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LBM_ABI_VERSION 2 /* 2: lbm_config.omega is a double */
+#define LBM_ABI_VERSION 3 /* 2: lbm_config.omega is a double; 3: lbm_config.abi_version, checked by lbm_create */
 
 typedef enum {
     LBM_OK = 0,
@@ -92,7 +92,11 @@ typedef struct {
     int32_t halo;             /* ghost rows kept above and below (0 for a single domain) */
     int32_t top_edge;         /* lbm_yedge for row 0 */
     int32_t bottom_edge;      /* lbm_yedge for row N-1 */
-    int32_t reserved[4];
+    int32_t abi_version;      /* = LBM_ABI_VERSION of the header the caller was built against.
+                                 sizeof(lbm_config) did not change when omega became a double (ABI 2),
+                                 so struct_size alone cannot tell an ABI-1 caller apart: lbm_create
+                                 rejects any other value here (an older caller leaves 0) */
+    int32_t reserved[3];
 } lbm_config;
 
 typedef struct lbm_solver lbm_solver;
@@ -147,9 +151,9 @@ int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame);
  * variant renders into a static device array inside the library instead (one copy of
  * LBM_NOALLOC_FRAME_MAX_BYTES per GPU, resolved in lbm_create, held until the process ends) and
  * calls no hipMalloc / hipFree / allocating routine.  Limits: N*M*3 <= LBM_NOALLOC_FRAME_MAX_BYTES
- * (otherwise LBM_ERR_UNSUPPORTED, state untouched); `frame` must be page-locked host memory
- * (lbm_host_alloc) or device memory (a pageable one is rejected: LBM_ERR_INVALID); NULL = plain
- * step.  All solvers on one GPU share that GPU's array: calls whose frames are in flight at the
+ * (otherwise LBM_ERR_UNSUPPORTED); `frame` must be page-locked host memory (lbm_host_alloc) or
+ * device memory (a pageable one is rejected: LBM_ERR_INVALID); NULL = plain step.  Every check that
+ * can fail runs BEFORE the step: an error return leaves the state untouched.  All solvers on one GPU share that GPU's array: calls whose frames are in flight at the
  * same time on one GPU (different solvers / streams, no lbm_sync between) race; calls on one
  * solver are ordered by its stream.  Results are identical to lbm_fused_collide_stream_display. */
 #define LBM_NOALLOC_FRAME_MAX_BYTES (32u << 20)

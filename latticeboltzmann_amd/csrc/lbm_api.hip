@@ -13,10 +13,6 @@
 
 using namespace lbm;
 
-#ifndef LBM_TB2_DEFAULT
-#define LBM_TB2_DEFAULT 0
-#endif
-
 static thread_local char g_err[512] = "";
 
 static int fail(int code, const char* fmt, ...) {
@@ -147,6 +143,9 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     if (cfg->struct_size != sizeof(lbm_config))
         return fail(LBM_ERR_INVALID, "lbm_config.struct_size %u != %zu", cfg->struct_size,
                     sizeof(lbm_config));
+    if (cfg->abi_version != LBM_ABI_VERSION)
+        return fail(LBM_ERR_INVALID, "lbm_config.abi_version %d != %d: the caller was built against another "
+                                     "lbm_hip.h (omega is a double since ABI 2)", cfg->abi_version, LBM_ABI_VERSION);
     if (cfg->N < 1 || cfg->M < 2) return fail(LBM_ERR_INVALID, "need N >= 1 and M >= 2");
     if (cfg->inner_timesteps < 1 || cfg->inner_timesteps > 64)
         return fail(LBM_ERR_INVALID, "inner_timesteps must be in [1, 64]");
@@ -344,23 +343,14 @@ int lbm_halo_valid(lbm_solver* s, int* rows) {
     return LBM_OK;
 }
 
-// Deepest launch in use.  Automatic: TB_DEFAULT_T, but the plain kernel for grids below 2^17 cells,
-// where both are bound by launch latency alike (128 x 256: 8.3 GLUPS either way; from 400 x 800 on
-// the LDS kernel wins: 62 against 56 GLUPS).
-// Which LDS kernel runs a launch of depth t: lbm_tb2.hip (two levels per wave) where it is
-// instantiated, lbm_tb.hip otherwise.  LBM_TB2=0 in the environment forces the older kernel
-// (development comparisons).
 static hipError_t launch_deep(lbm_solver* s, int t, int r0, int nrows) {
-    static const int use2 = [] {
-        const char* e = getenv("LBM_TB2");
-        return e ? atoi(e) : LBM_TB2_DEFAULT;
-    }();
-    if (use2 && tb2_has_depth(t))
-        return launch_step_tb2(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, s->geo, s->xmode, s->half, t, r0,
-                               nrows, s->tb_rows, s->stream);
     return launch_step_tb(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, s->geo, s->xmode, s->half, t, r0, nrows,
                           s->tb_rows, s->stream);
 }
+
+// Deepest launch in use.  Automatic: TB_DEFAULT_T, but the plain kernel for grids below 2^17 cells,
+// where both are bound by launch latency alike (128 x 256: 8.3 GLUPS either way; from 400 x 800 on
+// the LDS kernel wins: 62 against 56 GLUPS).
 
 static int depth_cap(const lbm_solver* s) {
     if (s->xmode == XMODE_CUDA) return 1;  // the compatibility mode only exists in the plain kernel
@@ -647,17 +637,31 @@ int lbm_host_free(void* host_ptr) {
     return LBM_OK;
 }
 
+// A frame is rendered from the state AFTER the outer iteration, which at a seam needs one valid
+// ghost row then: checked before the step, so that an error return leaves the state untouched.
+static int check_frame_after_step(lbm_solver* s) {
+    if (seam_top(s) || seam_bot(s)) {
+        const int consumed = s->pulled ? s->T : s->T - 1;  // the first update after an upload only collides
+        if (s->ghost_valid - consumed < 1)
+            return fail(LBM_ERR_INVALID, "a frame after this outer iteration needs %d valid ghost rows, %d are "
+                                         "left: exchange halos first", consumed + 1, s->ghost_valid);
+    }
+    return LBM_OK;
+}
+
 int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame) {
     ENTER(s);
+    const size_t bytes = (size_t)s->geo.N * s->geo.M * 3;
+    if (frame) {
+        int rc = check_frame_after_step(s);
+        if (rc) return rc;
+        if (!s->frame_dev) HIPCHK(hipMalloc((void**)&s->frame_dev, bytes));
+    }
     int rc = lbm_fused_collide_stream(s, 1);
     if (rc || !frame) return rc;
-    rc = check_window(s, 0, s->geo.N, 0, s->geo.M);
-    if (rc) return rc;
-    const size_t bytes = (size_t)s->geo.N * s->geo.M * 3;
-    if (!s->frame_dev) HIPCHK(hipMalloc((void**)&s->frame_dev, bytes));
     HIPCHK(launch_observe(s->buf[s->cur], s->mask, s->geo, s->xmode, s->half, s->pulled, 0, s->geo.N, 0,
                           s->geo.M, nullptr, nullptr, nullptr, s->frame_dev, s->stream));
-    HIPCHK(hipMemcpyAsync(frame, s->frame_dev, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipMemcpyAsync(frame, s->frame_dev, bytes, hipMemcpyDefault, s->stream));  // host or device frame
     return LBM_OK;
 }
 
@@ -682,16 +686,15 @@ int lbm_fused_collide_stream_display_noalloc(lbm_solver* s, uint8_t* frame) {
         if (pe != hipSuccess || at.type == hipMemoryTypeUnregistered)
             return fail(LBM_ERR_INVALID, "frame must be page-locked host memory (lbm_host_alloc) or device "
                                          "memory: a pageable destination makes the runtime stage the copy");
-        int rc = check_window(s, 0, s->geo.N, 0, s->geo.M);
+        int rc = check_frame_after_step(s);  // every check that can fail comes before the step
         if (rc) return rc;
     }
     int rc = lbm_fused_collide_stream(s, 1);
     if (rc || !frame) return rc;
-    rc = check_window(s, 0, s->geo.N, 0, s->geo.M);
-    if (rc) return rc;
     HIPCHK(launch_observe(s->buf[s->cur], s->mask, s->geo, s->xmode, s->half, s->pulled, 0, s->geo.N, 0,
                           s->geo.M, nullptr, nullptr, nullptr, (uint8_t*)s->scratch, s->stream));
-    HIPCHK(hipMemcpyAsync(frame, s->scratch, bytes, hipMemcpyDeviceToHost, s->stream));
+    // hipMemcpyDefault: `frame` may be page-locked host memory or device memory
+    HIPCHK(hipMemcpyAsync(frame, s->scratch, bytes, hipMemcpyDefault, s->stream));
     return LBM_OK;
 }
 

@@ -11,10 +11,6 @@ constexpr int TB_DEFAULT_T = 6;  // deepest launch used unless lbm_set_tuning sa
 constexpr long long TB_MIN_CELLS = 1 << 17;  // smaller grids: plain kernel (automatic tuning only)
 hipError_t launch_step_tb(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
                           bool half, int T, int row0, int nrows, int Ry, hipStream_t st);
-// two time levels per wave and row (lbm_tb2.hip); hipErrorNotSupported for other depths
-hipError_t launch_step_tb2(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
-                           bool half, int T, int row0, int nrows, int Ry, hipStream_t st);
-bool tb2_has_depth(int T);
 hipError_t launch_collide(void* f, const uint64_t* mask, const Geom& geo, int xmode, bool half,
                           int row0, int nrows, hipStream_t st);
 hipError_t launch_observe(const void* g, const uint64_t* mask, const Geom& geo, int xmode, bool half,

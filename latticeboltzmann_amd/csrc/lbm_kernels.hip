@@ -1,4 +1,5 @@
 // gfx950 kernels of the D2Q9 BGK path and their launchers.  Layout and numerics: lbm_device.h.
+#include <algorithm>
 #include <cstdlib>
 
 #include "lbm_internal.h"
@@ -301,9 +302,21 @@ static unsigned step_lds_cap(bool half) {
 template <typename T>
 static hipError_t launch_step_t(const T* gin, T* gout, const uint64_t* mask, const Geom& geo,
                                 int xmode, int row0, int nrows, hipStream_t st) {
-    if ((long long)nrows * geo.Mb >= (1ll << 31) - 4) return hipErrorInvalidValue;  // 1.3e11 cells
+    if (nrows <= 0) return hipSuccess;
+    // HIP refuses a launch of 2^32 threads or more, i.e. 2^26 single-wave workgroups (4.3e9 cells: an
+    // fp16 grid of that size fits the 288 GB): such a range goes in several launches, split by rows
+    // (rows of one update are independent).
+    const long long max_tiles = (1ll << 26) - 1;
+    if (geo.Mb > max_tiles) return hipErrorInvalidValue;  // one row alone: M > 4.3e9
+    if ((long long)nrows * geo.Mb > max_tiles) {
+        const int rows_per = (int)(max_tiles / geo.Mb);
+        for (int r = 0; r < nrows; r += rows_per) {
+            const hipError_t e = launch_step_t(gin, gout, mask, geo, xmode, row0 + r, std::min(rows_per, nrows - r), st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     const unsigned nwg = (unsigned)((long long)nrows * geo.Mb);  // one single-wave workgroup per tile
-    if (nwg == 0) return hipSuccess;
     const unsigned lds = step_lds_cap(sizeof(T) == 2);
     const FastDiv by_mb = make_fastdiv(geo.Mb);
     if (xmode == XMODE_PERIODIC)

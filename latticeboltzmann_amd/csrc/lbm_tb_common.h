@@ -1,5 +1,5 @@
 // Shared pieces of the LDS temporal-blocking kernels (lbm_tb.hip: one level per wave and row;
-// lbm_tb2.hip: two levels per wave and row).
+// tools/lbm_tb2.hip: two levels per wave and row, not built).
 #pragma once
 #include <type_traits>
 

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LBM_HIP_LIB", os.path.join(_HERE, "liblbm_hip.so"))  # env: dev experiments
 
-ABI_VERSION = 2  # include/lbm_hip.h LBM_ABI_VERSION
+ABI_VERSION = 3  # include/lbm_hip.h LBM_ABI_VERSION
 BOUNDARY_REFERENCE, BOUNDARY_PERIODIC, BOUNDARY_CUDA_KERNEL = 0, 1, 2
 YEDGE_DOMAIN, YEDGE_SEAM = 0, 1
 STORE_F32, STORE_F16 = 0, 1
@@ -65,7 +65,7 @@ class lbm_config(ctypes.Structure):
         ("M", ctypes.c_int32), ("omega", ctypes.c_double), ("inner_timesteps", ctypes.c_int32),
         ("boundary", ctypes.c_int32), ("storage", ctypes.c_int32), ("halo", ctypes.c_int32),
         ("top_edge", ctypes.c_int32), ("bottom_edge", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("abi_version", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
     ]
 
 
@@ -176,6 +176,7 @@ class Solver:
         self._L = load_library()
         cfg = lbm_config()
         cfg.struct_size = ctypes.sizeof(lbm_config)
+        cfg.abi_version = ABI_VERSION
         cfg.device = device
         cfg.N, cfg.M = int(N), int(M)
         cfg.omega = float(omega)
@@ -251,9 +252,15 @@ class Solver:
             assert frame.shape == (self.N, self.M, 3), frame.shape
         _check(self._L.lbm_fused_collide_stream_display(self._h, _bptr(frame)))
 
-    def fused_collide_stream_display_noalloc(self, frame=None):
+    def fused_collide_stream_display_noalloc(self, frame=None, device_ptr=None):
         """The same without any allocation in the library (static device scratch): `frame` must be
-        page-locked (pagelocked_empty) and at most NOALLOC_FRAME_MAX_BYTES."""
+        page-locked (pagelocked_empty) and at most NOALLOC_FRAME_MAX_BYTES.  device_ptr: the address
+        of N*M*3 bytes of DEVICE memory to receive the frame instead (e.g. tensor.data_ptr())."""
+        if device_ptr is not None:
+            assert frame is None
+            p = ctypes.cast(ctypes.c_void_p(int(device_ptr)), ctypes.POINTER(ctypes.c_uint8))
+            _check(self._L.lbm_fused_collide_stream_display_noalloc(self._h, p))
+            return
         if frame is not None:
             assert frame.dtype == np.uint8 and frame.flags.c_contiguous
             assert frame.shape == (self.N, self.M, 3), frame.shape

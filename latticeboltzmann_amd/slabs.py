@@ -10,16 +10,29 @@ Schedule of one cycle (halo = H), on the compute stream C and the communication 
     C: last d updates in one jump, edge rows only: [0, H) and [N-H, N)   -> event E1
     K: wait E1; grouped send/recv of those rows into the neighbours' ghost rows -> event E2
     C: the same jump for the interior rows [H, N-H)  (runs while the halos travel)
-    C: wait E2
+    host: wait for E2 (bounded) before the next cycle's first launch is enqueued
+Every wait on this path is a HOST-side poll with a deadline (`SlabSolver.timeout_s`): the compute
+stream never holds a device-side barrier on another stream's event, so its forward progress does not
+depend on how the runtime places streams on hardware queues, and a rank that is stuck raises
+SlabTimeout naming the wait, its rank and the stream states instead of blocking for ever (DESIGN.md
+section 6 has the round-2 hang this answers).  The host is released as soon as the exchange is done,
+i.e. while the interior jump still runs, so the compute stream does not run dry.
 d = 1 with the plain kernel; with the LDS kernel (tb_max_depth > 1) d = min(tb_max_depth, H), so a
 cycle of H <= 6 updates is three launches: two edge bands, then the interior.
 The exchange is a grouped torch.distributed send/recv (RCCL over xGMI on the GPU box, gloo in the
 CPU tests): `exchange_halos` below is backend-agnostic and is what tests/test_slabs_gloo.py drives.
 There is no reduction or other collective on the data path.
 """
+import os
+import time
+
 import numpy as np
 
 from . import lb_hip_kernel as hk
+
+
+class SlabTimeout(RuntimeError):
+    """A bounded wait of the slab schedule ran out (a hang made visible)."""
 
 
 def init_process_group_rccl(device, **kw):
@@ -30,9 +43,12 @@ def init_process_group_rccl(device, **kw):
     Stream priorities are deliberately left alone.  Round 2 tried RCCL's own stream and the
     communication stream at high priority, so that the halo messages would not queue behind the
     interior launch they overlap with; on this runtime (ROCm 7.x, 4 hardware queues per process)
-    either of the two made the schedule hang now and then -- 4 of 4 randomised soaks
-    (tools/stress_slabs.py) stopped within 70 cases with the compute stream waiting for ever,
-    against 0 of 500 cases with default priorities -- and the measured gain had been 0.1 %."""
+    either of the two made the schedule hang now and then -- 3 of 4 randomised soaks
+    (tools/stress_slabs.py) stopped within 70 cases, every time with the host in
+    `compute.synchronize()` AFTER `compute.wait_event(E2)` had been enqueued: the compute stream
+    never drained, against 0 of 1650 cases with default priorities -- and the measured gain had been
+    0.1 %.  Since round 3 the compute stream no longer waits for E2 on the device at all (module
+    docstring)."""
     import torch
     import torch.distributed as dist
     dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device}"), **kw)
@@ -149,7 +165,9 @@ class SlabSolver:
         self.solver.set_stream(self.compute.cuda_stream)
         self._tensors = {}
         self._fresh = True
-        self._pending = None  # event the compute stream must wait for before the next update
+        self._pending = None  # event (end of the halo exchange) the next update has to wait for
+        # deadline of every host-side wait on this path, seconds
+        self.timeout_s = float(os.environ.get("LBM_SLAB_TIMEOUT_S", "3600"))
         # gloo cannot send/recv device memory: stage the halos through the host (no overlap).
         # Only for rehearsing several ranks on one GPU; RCCL moves device memory directly.
         if host_staged is None:
@@ -188,9 +206,30 @@ class SlabSolver:
             self._tensors[ptr] = t
         return t
 
+    def _bounded_wait(self, what, done):
+        """Poll `done()` until it is true or `timeout_s` has passed (then: SlabTimeout).  A poll, not
+        hipStreamSynchronize / hipEventSynchronize: those cannot be bounded, and in round 2's hangs
+        a second thread's stream query blocked behind the main thread's synchronize."""
+        t0 = time.monotonic()
+        spins = 0
+        while not done():
+            spins += 1
+            if spins > 200:  # the first ~200 polls spin: an exchange is tens of microseconds
+                time.sleep(0.0002)
+                if time.monotonic() - t0 > self.timeout_s:
+                    raise SlabTimeout(
+                        f"rank {self.rank}/{self.world} (device {self.device}): {what} not complete after "
+                        f"{self.timeout_s:.0f} s; halo_valid={self.solver.halo_valid}, "
+                        f"exchange pending={self._pending is not None}")
+
     def _wait_pending(self):
+        """The ghost rows of the last exchange must have arrived before the next update reads them:
+        a host-side, bounded wait for E2 (the interior jump is still running on the compute stream
+        meanwhile, so nothing runs dry).  Completion of E2 seen by the host orders the exchange's
+        writes before every kernel launched afterwards."""
         if self._pending is not None:
-            self.compute.wait_event(self._pending)
+            ev = self._pending
+            self._bounded_wait("halo exchange (event E2 on the communication stream)", ev.query)
             self._pending = None
 
     def step(self, n=1):
@@ -257,8 +296,8 @@ class SlabSolver:
 
     def sync(self):
         self._wait_pending()
-        self.compute.synchronize()
-        self.comm.synchronize()
+        self._bounded_wait("compute stream drain", self.compute.query)
+        self._bounded_wait("communication stream drain", self.comm.query)
 
     # -- readback (this rank's rows) ---------------------------------------------------------------
     def read_moments(self, rows=None, cols=None):

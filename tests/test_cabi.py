@@ -29,7 +29,7 @@ def test_header_symbols_are_exported_and_bound():
     out = subprocess.check_output(["nm", "-D", "--defined-only", hk.LIB_PATH], text=True)
     exported = set(re.findall(r"\bT (lbm_[a-z_0-9]+)", out))
     assert set(declared) <= exported
-    assert L.lbm_abi_version() == hk.ABI_VERSION == 2
+    assert L.lbm_abi_version() == hk.ABI_VERSION == 3
 
 
 def test_config_struct_layout_matches_c(tmp_path):
@@ -46,6 +46,24 @@ def test_config_struct_layout_matches_c(tmp_path):
     vals = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
     assert vals[0] == ctypes.sizeof(hk.lbm_config)
     assert vals[1:] == [getattr(hk.lbm_config, f).offset for f in fields]
+
+
+def test_create_rejects_a_caller_built_against_another_abi():
+    """sizeof(lbm_config) did not change when omega became a double, so struct_size cannot tell an
+    ABI-1 caller apart; abi_version can (checked before any device is touched: runs without a GPU)."""
+    from latticeboltzmann_amd import lb_hip_kernel as hk
+    L = hk.load_library()
+    cfg = hk.lbm_config()
+    cfg.struct_size = ctypes.sizeof(hk.lbm_config)
+    cfg.N, cfg.M, cfg.omega, cfg.inner_timesteps = 8, 8, 0.5, 1
+    h = ctypes.c_void_p()
+    for v in (0, 1, 2, 4):  # 0 = what a caller of ABI <= 2 leaves in the then-reserved field
+        cfg.abi_version = v
+        assert L.lbm_create(ctypes.byref(cfg), ctypes.byref(h)) == 1  # LBM_ERR_INVALID
+        assert b"abi_version" in L.lbm_last_error() and not h.value
+    cfg.abi_version = hk.ABI_VERSION
+    cfg.struct_size -= 4
+    assert L.lbm_create(ctypes.byref(cfg), ctypes.byref(h)) == 1 and b"struct_size" in L.lbm_last_error()
 
 
 def test_header_is_plain_c():

@@ -164,3 +164,23 @@ def test_slab_rows_cover():
     assert neighbours(2, 0, "periodic") == (1, 1)
     assert neighbours(4, 0, "reference") == (None, 1)
     assert neighbours(4, 3, "reference") == (2, None)
+
+
+def test_bounded_wait_raises_instead_of_hanging():
+    """Every wait of the slab schedule is a host-side poll with a deadline (slabs.py): a wait that
+    never completes raises SlabTimeout naming the wait and the rank; one that does returns."""
+    import types
+    from latticeboltzmann_amd import slabs
+    fake = types.SimpleNamespace(rank=3, world=8, device=3, timeout_s=0.05, _pending=object(),
+                                 solver=types.SimpleNamespace(halo_valid=2))
+    with pytest.raises(slabs.SlabTimeout, match=r"rank 3/8 .*halo exchange.* not complete"):
+        slabs.SlabSolver._bounded_wait(fake, "halo exchange (event E2)", lambda: False)
+    calls = []
+    slabs.SlabSolver._bounded_wait(fake, "x", lambda: calls.append(1) or len(calls) > 300)
+    assert len(calls) == 301
+    # _wait_pending polls the event and clears it
+    ev = types.SimpleNamespace(query=lambda: True)
+    fake._pending = ev
+    fake._bounded_wait = lambda what, done: slabs.SlabSolver._bounded_wait(fake, what, done)
+    slabs.SlabSolver._wait_pending(fake)
+    assert fake._pending is None

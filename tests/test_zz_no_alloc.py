@@ -84,3 +84,48 @@ def test_noalloc_display_rejects_what_it_cannot_serve():
     assert np.array_equal(f, s.render())
     hk.release_pagelocked(f)
     s.close()
+
+
+def test_noalloc_display_into_device_memory():
+    """`frame` may be device memory too (the copy is issued with hipMemcpyDefault)."""
+    import torch
+    from latticeboltzmann_amd import lb_hip_kernel as hk
+    N, M = 120, 200
+    a, b = _pair(N, M, 2, "reference", 5)
+    dev = torch.full((N, M, 3), 5, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    fa = hk.pagelocked_empty((N, M, 3))
+    for it in range(2):
+        a.fused_collide_stream_display_noalloc(fa)
+        b.fused_collide_stream_display_noalloc(device_ptr=dev.data_ptr())
+        a.sync()
+        b.sync()
+        assert np.array_equal(dev.cpu().numpy(), fa) and fa.any()
+    hk.release_pagelocked(fa)
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("entry", ["fused_collide_stream_display", "fused_collide_stream_display_noalloc"])
+def test_display_error_at_a_seam_leaves_the_state_untouched(entry):
+    """At a slab seam a frame after the step needs one more valid ghost row: that is checked BEFORE
+    the step, so the error return leaves the step count and the state as they were."""
+    from latticeboltzmann_amd import lb_hip_kernel as hk
+    N, M = 40, 70
+    s = hk.Solver(N, M, 0.3, boundary="periodic", halo=1, top_edge=hk.YEDGE_SEAM, bottom_edge=hk.YEDGE_SEAM)
+    s.set_surroundings(onp.ambient())
+    s.upload_cells(onp.perturbed_cells(N + 2, M, seed=3), -1)
+    s.halo_mark_filled()
+    f = hk.pagelocked_empty((N, M, 3))
+    getattr(s, entry)(f)   # first update after an upload only collides: consumes no ghost row
+    s.sync()
+    assert s.steps_done == 1 and s.halo_valid == 1
+    before = s.read_cells()
+    with pytest.raises(RuntimeError, match="valid ghost rows"):
+        getattr(s, entry)(f)   # would leave no valid ghost row to render from
+    assert s.steps_done == 1 and s.halo_valid == 1
+    assert np.array_equal(s.read_cells(), before)
+    getattr(s, entry)(None)    # the plain step is still possible
+    assert s.steps_done == 2
+    hk.release_pagelocked(f)
+    s.close()

@@ -58,6 +58,10 @@ __global__ __launch_bounds__(256) void kstream(const float* __restrict__ in, flo
 #pragma unroll
         for (int k = 0; k < 9; k++) __builtin_nontemporal_store(d[k], p + 64 * k);
     };
+    if (EXTRA == 5) {  // de-phase the waves of a CU once: a pseudo-random start delay of 0..15 x ~500 cycles
+        const int phase = (int)(((blockIdx.x * 4u + (threadIdx.x >> 6)) * 2654435761u) >> 28);
+        for (int i = 0; i < phase; i++) __builtin_amdgcn_s_sleep(8);
+    }
 #pragma unroll
     for (int d = 0; d < PF; d++) load(d, v[d]);
     // PF+1 register sets, rotated by unrolling the loop PF+1 times
@@ -229,7 +233,9 @@ int main(int argc, char** argv) {
     if (argc > 2 && !strcmp(argv[2], "dyn")) {  // queue-fed persistent waves against both ends
         run<SHORT, 0>("short", a, b, nchunks, 4, 36u << 10, rounds);
         run<SWEEP, 0>("long/sweep", a, b, nchunks, 4, 36u << 10, rounds);
-        run_dyn<1>("long/queue", a, b, nchunks, 4, 36u << 10, rounds);
+        run<SWEEP, 0, 0, 5>("long/sweep dephased", a, b, nchunks, 4, 36u << 10, rounds);
+        run<SWEEP, 0, 2, 0>("long/sweep write-only", a, b, nchunks, 4, 36u << 10, rounds);
+        run<SWEEP, 0, 2, 5>("long/sweep write-only dephased", a, b, nchunks, 4, 36u << 10, rounds);
         run_dyn<2>("long/queue", a, b, nchunks, 4, 36u << 10, rounds);
         run_dyn<4>("long/queue", a, b, nchunks, 4, 36u << 10, rounds);
         run_dyn<16>("long/queue", a, b, nchunks, 4, 36u << 10, rounds);

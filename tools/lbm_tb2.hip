@@ -1,3 +1,9 @@
+// NOT BUILT, NOT SHIPPED (moved out of the product library in round 3).  The two-levels-per-wave variant
+// of the LDS temporal-blocking kernel from round 2: bit-identical to lbm_tb.hip but slower (T = 6:
+// 276-277 against 318 GLUPS) and without that kernel's later improvements (sink-style collide2_to,
+// immediate-only ring offsets, scaled quotients, ballots).  Kept as a record of the design
+// (profiles/r02_tb_experiments.md); to revive it, put it back beside lbm_tb.hip, add it to SRC in
+// latticeboltzmann_amd/csrc/Makefile and re-declare launch_step_tb2 / tb2_has_depth in lbm_internal.h.
 // Temporal blocking, second design: TWO time levels per wave and row.
 //
 // lbm_tb.hip gives every time level its own waves and passes every level through LDS: T-1 ring
