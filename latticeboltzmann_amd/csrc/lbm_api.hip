@@ -125,6 +125,18 @@ static size_t elem_size(const lbm_solver* s) { return s->half ? 2 : 4; }
 static bool seam_top(const lbm_solver* s) { return s->geo.top == YEDGE_GHOST; }
 static bool seam_bot(const lbm_solver* s) { return s->geo.bot == YEDGE_GHOST; }
 
+// Unused 2304-byte blocks at the end of every row of the field buffers (never read or written).
+// LBM_ROW_PAD in the environment overrides it (development sweeps).
+static int row_pad_blocks(int Mb) {
+    static const int env = [] {
+        const char* e = getenv("LBM_ROW_PAD");
+        return e ? atoi(e) : -1;
+    }();
+    if (env >= 0) return env;
+    (void)Mb;
+    return 0;
+}
+
 extern "C" {
 
 int lbm_abi_version(void) { return LBM_ABI_VERSION; }
@@ -183,7 +195,7 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     g.M = cfg->M;
     g.Mb = (cfg->M + LANES - 1) / LANES;
     g.G = cfg->halo;
-    g.rowStride = (long long)g.Mb * CHUNK;
+    g.rowStride = (long long)(g.Mb + row_pad_blocks(g.Mb)) * CHUNK;
     const int dom = cfg->boundary == LBM_BOUNDARY_PERIODIC ? YEDGE_WRAP : YEDGE_DOMAIN;
     g.top = st ? YEDGE_GHOST : dom;
     g.bot = sb ? YEDGE_GHOST : dom;

@@ -124,7 +124,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     const int nchunks_ = gridDim.x / nstrips;
     const int strip = REMAP == 2 ? wg / nchunks_ : wg % nstrips;
     const int chunk = REMAP == 2 ? wg % nchunks_ : wg / nstrips;
-    const int xo = strip * C::SW;  // first stored column
+    const int xo = strip * C::SW - C::SH;  // first stored column (strip 0: clipped at column 0)
     const int y0 = row0 + chunk * Ry;
     const int y1 = min(y0 + Ry, row0 + nrows);
     const int N = geo.N, M = geo.M, G = geo.G;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
         int xn;                                                       // storage column
         if (XMODE == XMODE_PERIODIC) { xn = x % M; if (xn < 0) xn += M; }
         else xn = min(max(x, 0), M - 1);  // outside the domain: a valid address, never stored
-        stored[c] = x >= xo && x < xo + C::SW && x < M;
+        stored[c] = x >= xo && x >= 0 && x < xo + C::SW && x < M;
         // level s is only right s-1 columns inside the window (see the header): the columns
         // beyond compute on stale ring contents and nobody reads what they produce
         const int wc = j * (64 * CPL) + c * 64 + lane;
@@ -515,7 +515,7 @@ template <int XMODE, int T, int NB, int CPL, int MARG, typename ST>
 static void launch_tb_t(const ST* gin, ST* gout, const uint64_t* mask, const Geom& geo, int row0,
                         int nrows, int Ry, hipStream_t st) {
     using C = TB<T, NB, CPL, MARG>;
-    const int nstrips = (geo.M + C::SW - 1) / C::SW;
+    const int nstrips = (geo.M + C::SH + C::SW - 1) / C::SW;
     if (Ry <= 0) {
         // per process and instantiation: all devices of a node are the same part (a benign race:
         // concurrent first calls compute the same value)

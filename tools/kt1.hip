@@ -30,7 +30,7 @@ __device__ __forceinline__ long long chunk_off(const Lay& L, int y, int xb) {
     return (long long)pn * L.panelStride + ((long long)y * L.S + xi) * CHUNK;
 }
 
-enum { K_STEP = 0, K_COPY = 1, K_COPY3 = 2, K_COPY3S = 3, K_STEP2 = 4 };
+enum { K_STEP = 0, K_COPY = 1, K_COPY3 = 2, K_COPY3S = 3, K_STEP2 = 4, K_COPY3W = 5, K_COPY3WS = 6 };  // 3W: read the own chunk, WRITE the three 768-byte pieces to rows y-1, y, y+1 (push in y); 3WS: the same with lane-shifted loads (pull in x)
 // INPLACE: the destination is the source location(s); for K_COPY3* that means the three 768-byte
 // pieces go back where they came from (rows y-1, y, y+1), as an AA-pattern odd step would write.
 template <int KIND, bool INPLACE>
@@ -99,6 +99,23 @@ __global__ __launch_bounds__(64) void kt1(const float* __restrict__ gin, float* 
         float* o = (INPLACE ? const_cast<float*>(gin) : gout) + o0[1] + lane;
 #pragma unroll
         for (int k = 0; k < Q; k++) __builtin_nontemporal_store(a[k], o + 64 * k);
+        return;
+    }
+    if (KIND == K_COPY3W || KIND == K_COPY3WS) {
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            const int dx = dx_of(k), sl = slot_of(k) * LANES;
+            long long off;
+            if (KIND == K_COPY3W || dx == 0) off = o0[1] + lane;
+            else if (dx == -1) off = lane == 63 ? om[1] : o0[1] + lane + 1;
+            else off = lane == 0 ? op[1] + 63 : o0[1] + lane - 1;
+            a[k] = __builtin_nontemporal_load(gin + off + sl);
+        }
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            const int dy = dy_of(k), sl = slot_of(k) * LANES;
+            __builtin_nontemporal_store(a[k], gout + o0[1 - dy] + lane + sl);  // to row y + dy
+        }
         return;
     }
     const float* src[Q];
@@ -198,6 +215,8 @@ int main(int argc, char** argv) {
     vars.push_back({"copy 3rows inplace", kt1<K_COPY3, true>, Mb, true, false, step_bytes});
     vars.push_back({"copy 3rows shifted 2buf", kt1<K_COPY3S, false>, Mb, false, false, step_bytes});
     vars.push_back({"copy 3rows shifted inplace", kt1<K_COPY3S, true>, Mb, true, false, step_bytes});
+    vars.push_back({"copy chunk -> 3rows", kt1<K_COPY3W, false>, Mb, false, false, step_bytes});
+    vars.push_back({"copy chunk shifted -> 3rows", kt1<K_COPY3WS, false>, Mb, false, false, step_bytes});
     vars.push_back({"copy 3rows 2buf P=16", kt1<K_COPY3, false>, 16, false, false, step_bytes});
     vars.push_back({"copy 3rows inplace P=16", kt1<K_COPY3, true>, 16, true, false, step_bytes});
 
