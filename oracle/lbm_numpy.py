@@ -17,12 +17,18 @@ What it restates (all citations are into /root/reference):
   loop order          latticeboltzmann.jl:107-120   (moments, collide, display, stream, reflect)
   cylinder scene      latticeboltzmann.jl:25-32,51
 
-Pinning status.  The reference cannot be imported here (top-level `import pycuda.autoinit`,
-latticeboltzmann.py:11, and the numpy path is commented out), and it ships no golden fields.
-What the reference itself pins, and tests/test_oracle.py checks: the four lattice asserts
-(:28-29, :33-34), the two conservation asserts (:93-94) and the obstacle masks of its two scene
-images.  FIELD PARITY IS UNPINNED by the reference: the golden fields under tests/golden/ were
-produced by this restatement (tests/golden/make_golden.py).
+Pinning status: PINNED to the reference's own text.  The reference cannot be imported as a module
+(top-level `import pycuda.autoinit`, latticeboltzmann.py:11, and the numpy path is commented out)
+and it ships no golden fields, but its numpy lines can be executed from its file:
+tests/golden/ref_extract.py reads /root/reference/latticeboltzmann.py at run time (storing none
+of it), takes :16-35, :80-95, :142 verbatim and the commented-out :98, :107-123, :180-183 with the
+`# ` removed, and steps them in the order of latticeboltzmann.jl:107-120.  The golden fields under
+tests/golden/ (fields_*.npz, sha_cyl400x800_reference.npz) are the OUTPUT OF THOSE LINES
+(tests/golden/make_golden.py), and tests/test_oracle.py checks that this restatement and its C
+twin reproduce them bit for bit (test_golden_fields, test_config1_cylinder_digests), live on
+further scenes in the build container (test_live_reference_text_equals_the_restatement), besides
+the four lattice asserts (:28-29, :33-34), the two conservation asserts (:93-94) and the obstacle
+masks of the reference's two scene images.
 
 `boundary="periodic"` has no counterpart in the reference (BASELINE.json configs 2-4 name a
 periodic channel); it replaces the stream step's edge rule by a wrap-around (np.roll).
