@@ -66,6 +66,22 @@ typedef enum {
                              (lbm_halo_*), no edge rule */
 } lbm_yedge;
 
+/* Velocity set.  Everything in this header describes D2Q9 unless it says otherwise. */
+typedef enum {
+    LBM_LATTICE_D2Q9 = 0,  /* latticeboltzmann.py:24-35 */
+    LBM_LATTICE_D2Q21 = 1  /* the draft's lattice, latticeboltzmann.jl:3-22 (r2 = 3/2, 21 weights and
+                              velocities (dy, dx) with |d| <= 3; opposite of k is 20-k).  Scoped: one
+                              update per launch, LBM_BOUNDARY_PERIODIC, LBM_STORE_F32, single domain.
+                              cells are float32 (N, M, 21); N, M >= 4.  Supported calls: create /
+                              destroy / set_stream, upload_blocked / upload_cells / read_blocked,
+                              init_equilibrium (row_offset / global_rows ignored), init_blocked_discs,
+                              fused_collide_stream[_timed], advance, sync, steps_done, read_cells,
+                              read_moments; the rest return LBM_ERR_UNSUPPORTED.  PARITY UNPINNED: the
+                              draft is not a runnable program and the reference holds no output of it;
+                              results are those of oracle/lbm_d2q21.py (the reference's numpy algorithm
+                              with the draft's tables), bit for bit. */
+} lbm_lattice;
+
 typedef enum {
     LBM_STORE_F32 = 0,
     LBM_STORE_F16 = 1 /* fp16 storage / fp32 compute, lb_cuda_kernel.cu:152-179 (half_enable).
@@ -96,7 +112,8 @@ typedef struct {
                                  sizeof(lbm_config) did not change when omega became a double (ABI 2),
                                  so struct_size alone cannot tell an ABI-1 caller apart: lbm_create
                                  rejects any other value here (an older caller leaves 0) */
-    int32_t reserved[3];
+    int32_t lattice;          /* lbm_lattice (0 = D2Q9) */
+    int32_t reserved[2];
 } lbm_config;
 
 typedef struct lbm_solver lbm_solver;

@@ -36,6 +36,8 @@ struct lbm_solver {
     lbm_config cfg;
     Geom geo;
     int xmode;
+    bool q21;     // LBM_LATTICE_D2Q21 (lbm_d2q21.hip): periodic, fp32, one update per launch
+    int Q;        // populations per cell: 9 or 21
     bool half;
     int T;
     int tb_max;   // deepest temporal-blocking launch (1 = never use the LDS kernel, 0 = automatic)
@@ -121,6 +123,11 @@ static int check(lbm_solver* s, DeviceScope& scope) {
         if (rc_ != LBM_OK) return rc_;    \
     } while (0)
 
+#define NOT_FOR_Q21(s, what)                                                                   \
+    do {                                                                                       \
+        if ((s)->q21) return fail(LBM_ERR_UNSUPPORTED, what " is not available for LBM_LATTICE_D2Q21"); \
+    } while (0)
+
 static size_t elem_size(const lbm_solver* s) { return s->half ? 2 : 4; }
 static bool seam_top(const lbm_solver* s) { return s->geo.top == YEDGE_GHOST; }
 static bool seam_bot(const lbm_solver* s) { return s->geo.bot == YEDGE_GHOST; }
@@ -170,6 +177,14 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     if (cfg->storage != LBM_STORE_F32 && cfg->storage != LBM_STORE_F16)
         return fail(LBM_ERR_INVALID, "unknown storage %d", cfg->storage);
     if (cfg->halo < 0 || cfg->halo > 64) return fail(LBM_ERR_INVALID, "halo must be in [0, 64]");
+    if (cfg->lattice != LBM_LATTICE_D2Q9 && cfg->lattice != LBM_LATTICE_D2Q21)
+        return fail(LBM_ERR_INVALID, "unknown lattice %d", cfg->lattice);
+    if (cfg->lattice == LBM_LATTICE_D2Q21) {
+        if (cfg->boundary != LBM_BOUNDARY_PERIODIC || cfg->storage != LBM_STORE_F32 || cfg->halo != 0 ||
+            cfg->top_edge != LBM_YEDGE_DOMAIN || cfg->bottom_edge != LBM_YEDGE_DOMAIN)
+            return fail(LBM_ERR_UNSUPPORTED, "LBM_LATTICE_D2Q21 is periodic, fp32, single-domain only");
+        if (cfg->N < 4 || cfg->M < 4) return fail(LBM_ERR_INVALID, "LBM_LATTICE_D2Q21 needs N >= 4 and M >= 4");
+    }
     const bool st = cfg->top_edge == LBM_YEDGE_SEAM, sb = cfg->bottom_edge == LBM_YEDGE_SEAM;
     if ((st || sb) && cfg->halo < 1) return fail(LBM_ERR_INVALID, "a seam edge needs halo >= 1");
     if ((st || sb) && cfg->N < cfg->halo) return fail(LBM_ERR_INVALID, "N must be >= halo");
@@ -187,6 +202,8 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     s->xmode = cfg->boundary == LBM_BOUNDARY_PERIODIC ? XMODE_PERIODIC
              : cfg->boundary == LBM_BOUNDARY_CUDA_KERNEL ? XMODE_CUDA : XMODE_REFERENCE;
     s->half = cfg->storage == LBM_STORE_F16;
+    s->q21 = cfg->lattice == LBM_LATTICE_D2Q21;
+    s->Q = s->q21 ? Q21 : Q;
     s->T = cfg->inner_timesteps;
     s->tb_max = 0;  // automatic (depth_cap)
     s->tb_rows = 0;  // 0 = chosen per launch (auto_chunk_rows)
@@ -195,7 +212,7 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     g.M = cfg->M;
     g.Mb = (cfg->M + LANES - 1) / LANES;
     g.G = cfg->halo;
-    g.rowStride = (long long)(g.Mb + row_pad_blocks(g.Mb)) * CHUNK;
+    g.rowStride = s->q21 ? (long long)g.Mb * Q21 * LANES : (long long)(g.Mb + row_pad_blocks(g.Mb)) * CHUNK;
     const int dom = cfg->boundary == LBM_BOUNDARY_PERIODIC ? YEDGE_WRAP : YEDGE_DOMAIN;
     g.top = st ? YEDGE_GHOST : dom;
     g.bot = sb ? YEDGE_GHOST : dom;
@@ -307,13 +324,16 @@ int lbm_upload_cells(lbm_solver* s, const float* cells, int row0, int nrows) {
         s->pulled = false;
         s->steps = 0;
     }
-    const size_t row_bytes = (size_t)s->geo.M * 9 * sizeof(float);
+    const size_t row_bytes = (size_t)s->geo.M * s->Q * sizeof(float);
     const int chunk = (int)std::max<size_t>(1, s->staging_bytes / row_bytes);
     if (row_bytes > s->staging_bytes) return fail(LBM_ERR_UNSUPPORTED, "row too long for staging");
     for (int r = 0; r < nrows; r += chunk) {
         const int n = std::min(chunk, nrows - r);
         HIPCHK(hipMemcpyAsync(s->staging, (const char*)cells + (size_t)r * row_bytes,
                               (size_t)n * row_bytes, hipMemcpyHostToDevice, s->stream));
+        if (s->q21)
+            HIPCHK(launch_q21_import_cells(s->buf[s->cur], s->geo, (const float*)s->staging, row0 + r, n, s->stream));
+        else
         HIPCHK(launch_import_cells(s->buf[s->cur], s->geo, s->half, (const float*)s->staging, row0 + r,
                                    n, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -328,6 +348,10 @@ int lbm_init_equilibrium(lbm_solver* s, float rho, float u_row, float u_col, flo
     s->open_update = false;
     s->steps = 0;
     s->ghost_valid = s->geo.G;
+    if (s->q21) {
+        HIPCHK(launch_q21_init_equilibrium(s->buf[s->cur], s->geo, rho, u_row, u_col, amp, seed, s->stream));
+        return LBM_OK;
+    }
     HIPCHK(launch_init_equilibrium(s->buf[s->cur], s->geo, s->half, rho, u_row, u_col, amp, seed,
                                    row_offset, global_rows, s->stream));
     return LBM_OK;
@@ -381,6 +405,17 @@ static int advance(lbm_solver* s, long long total, int max_depth) {
         return fail(LBM_ERR_INVALID, "an update opened by lbm_step_rows(finish = 0) is unfinished: "
                                      "finish it (finish != 0) before stepping further");
     const bool seam = seam_top(s) || seam_bot(s);
+    while (total > 0 && s->q21) {  // D2Q21: collide-only first update, then one update per launch
+        if (!s->pulled) {
+            HIPCHK(launch_q21_collide(s->buf[s->cur], s->mask, g, s->stream));
+            s->pulled = true;
+        } else {
+            HIPCHK(launch_q21_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->stream));
+            s->cur ^= 1;
+        }
+        s->steps++;
+        total--;
+    }
     while (total > 0) {
         if (!s->pulled) {
             HIPCHK(launch_collide(s->buf[s->cur], s->mask, g, s->xmode, s->half, -g.G, g.N + 2 * g.G, s->stream));
@@ -453,6 +488,7 @@ int lbm_advance(lbm_solver* s, int n_updates) {
 
 int lbm_set_tuning(lbm_solver* s, int tb_max_depth, int tb_rows) {
     ENTER(s);
+    NOT_FOR_Q21(s, "lbm_set_tuning");
     if (tb_max_depth < 0 || tb_max_depth > TB_MAX_T || tb_rows < 0)
         return fail(LBM_ERR_INVALID, "tb_max_depth must be in [0, %d] and tb_rows >= 0", TB_MAX_T);
     s->tb_max = tb_max_depth;
@@ -462,6 +498,7 @@ int lbm_set_tuning(lbm_solver* s, int tb_max_depth, int tb_rows) {
 
 int lbm_advance_rows(lbm_solver* s, int row0, int nrows, int depth, int finish) {
     ENTER(s);
+    NOT_FOR_Q21(s, "lbm_step_rows / lbm_advance_rows");
     int rc = check_rows(s, row0, nrows, true);
     if (rc) return rc;
     if (!s->pulled)
@@ -570,7 +607,8 @@ static int check_window(lbm_solver* s, int row0, int nrows, int col0, int ncols)
 static int observe(lbm_solver* s, int row0, int nrows, int col0, int ncols, float* cells, float* rho,
                    float* u, uint8_t* rgb) {
     if (nrows == 0 || ncols == 0) return LBM_OK;
-    const size_t per_row = (size_t)ncols * ((cells ? 36 : 0) + (rho ? 4 : 0) + (u ? 8 : 0) + (rgb ? 4 : 0));
+    const size_t cell_b = (size_t)s->Q * sizeof(float);
+    const size_t per_row = (size_t)ncols * ((cells ? cell_b : 0) + (rho ? 4 : 0) + (u ? 8 : 0) + (rgb ? 4 : 0));
     if (per_row == 0) return LBM_OK;
     if (per_row > s->staging_bytes) return fail(LBM_ERR_UNSUPPORTED, "row too long for staging");
     const int chunk = (int)std::max<size_t>(1, s->staging_bytes / per_row);
@@ -579,14 +617,18 @@ static int observe(lbm_solver* s, int row0, int nrows, int col0, int ncols, floa
         char* p = (char*)s->staging;
         float* dc = nullptr; float* dr = nullptr; float* du = nullptr; uint8_t* dg = nullptr;
         const size_t cells_n = (size_t)n * ncols;
-        if (cells) { dc = (float*)p; p += cells_n * 36; }
+        if (cells) { dc = (float*)p; p += cells_n * cell_b; }
         if (rho) { dr = (float*)p; p += cells_n * 4; }
         if (u) { du = (float*)p; p += cells_n * 8; }
         if (rgb) { dg = (uint8_t*)p; }
+        if (s->q21)
+            HIPCHK(launch_q21_observe(s->buf[s->cur], s->mask, s->geo, s->pulled, row0 + r, n, col0, ncols, dc, dr,
+                                      du, s->stream));
+        else
         HIPCHK(launch_observe(s->buf[s->cur], s->mask, s->geo, s->xmode, s->half, s->pulled, row0 + r, n,
                               col0, ncols, dc, dr, du, dg, s->stream));
         const size_t o = (size_t)r * ncols;
-        if (cells) HIPCHK(hipMemcpyAsync(cells + o * 9, dc, cells_n * 36, hipMemcpyDeviceToHost, s->stream));
+        if (cells) HIPCHK(hipMemcpyAsync(cells + o * s->Q, dc, cells_n * cell_b, hipMemcpyDeviceToHost, s->stream));
         if (rho) HIPCHK(hipMemcpyAsync(rho + o, dr, cells_n * 4, hipMemcpyDeviceToHost, s->stream));
         if (u) HIPCHK(hipMemcpyAsync(u + o * 2, du, cells_n * 8, hipMemcpyDeviceToHost, s->stream));
         if (rgb) HIPCHK(hipMemcpyAsync(rgb + o * 3, dg, cells_n * 3, hipMemcpyDeviceToHost, s->stream));
@@ -630,6 +672,7 @@ int lbm_read_blocked(lbm_solver* s, uint8_t* blocked, int row0, int nrows) {
 
 int lbm_render(lbm_solver* s, uint8_t* rgb, int row0, int nrows) {
     ENTER(s);
+    NOT_FOR_Q21(s, "lbm_render");
     if (!rgb) return fail(LBM_ERR_INVALID, "rgb is null");
     int rc = check_window(s, row0, nrows, 0, s->geo.M);
     if (rc) return rc;
@@ -663,6 +706,7 @@ static int check_frame_after_step(lbm_solver* s) {
 
 int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame) {
     ENTER(s);
+    if (frame) NOT_FOR_Q21(s, "a rendered frame");
     const size_t bytes = (size_t)s->geo.N * s->geo.M * 3;
     if (frame) {
         int rc = check_frame_after_step(s);
@@ -683,6 +727,7 @@ int lbm_fused_collide_stream_display(lbm_solver* s, uint8_t* frame) {
 // stage such a copy through buffers of its own.
 int lbm_fused_collide_stream_display_noalloc(lbm_solver* s, uint8_t* frame) {
     ENTER(s);
+    NOT_FOR_Q21(s, "lbm_fused_collide_stream_display_noalloc");
     const size_t bytes = (size_t)s->geo.N * s->geo.M * 3;
     if (frame) {
         if (bytes > (size_t)LBM_NOALLOC_FRAME_MAX_BYTES)
@@ -712,6 +757,7 @@ int lbm_fused_collide_stream_display_noalloc(lbm_solver* s, uint8_t* frame) {
 
 int lbm_halo_region(lbm_solver* s, int side, int recv, int next, void** device_ptr, size_t* bytes) {
     ENTER(s);
+    NOT_FOR_Q21(s, "lbm_halo_region");
     if (!device_ptr || !bytes || side < 0 || side > 1) return fail(LBM_ERR_INVALID, "bad argument");
     const int b = next ? (s->cur ^ 1) : s->cur;
     const Geom& g = s->geo;

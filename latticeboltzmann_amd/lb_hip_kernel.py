@@ -19,6 +19,8 @@ ABI_VERSION = 3  # include/lbm_hip.h LBM_ABI_VERSION
 BOUNDARY_REFERENCE, BOUNDARY_PERIODIC, BOUNDARY_CUDA_KERNEL = 0, 1, 2
 YEDGE_DOMAIN, YEDGE_SEAM = 0, 1
 STORE_F32, STORE_F16 = 0, 1
+LATTICE_D2Q9, LATTICE_D2Q21 = 0, 1
+_LATTICES = {"d2q9": (LATTICE_D2Q9, 9), "d2q21": (LATTICE_D2Q21, 21)}
 _BOUNDARIES = {"reference": BOUNDARY_REFERENCE, "periodic": BOUNDARY_PERIODIC,
                "cuda_kernel": BOUNDARY_CUDA_KERNEL}
 _STORAGE = {np.dtype(np.float32): STORE_F32, np.dtype(np.float16): STORE_F16}
@@ -65,7 +67,7 @@ class lbm_config(ctypes.Structure):
         ("M", ctypes.c_int32), ("omega", ctypes.c_double), ("inner_timesteps", ctypes.c_int32),
         ("boundary", ctypes.c_int32), ("storage", ctypes.c_int32), ("halo", ctypes.c_int32),
         ("top_edge", ctypes.c_int32), ("bottom_edge", ctypes.c_int32),
-        ("abi_version", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
+        ("abi_version", ctypes.c_int32), ("lattice", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
     ]
 
 
@@ -171,7 +173,9 @@ class Solver:
     """
 
     def __init__(self, N, M, omega, inner_timesteps=1, boundary="reference", dtype=np.float32,
-                 device=0, halo=0, top_edge=YEDGE_DOMAIN, bottom_edge=YEDGE_DOMAIN):
+                 device=0, halo=0, top_edge=YEDGE_DOMAIN, bottom_edge=YEDGE_DOMAIN, lattice="d2q9"):
+        """lattice="d2q21": the draft lattice of latticeboltzmann.jl:3-22 (periodic, float32, one
+        update per launch; cells are (N, M, 21); parity-unpinned, see include/lbm_hip.h)."""
         self._h = None
         self._L = load_library()
         cfg = lbm_config()
@@ -185,6 +189,7 @@ class Solver:
         cfg.storage = _STORAGE[np.dtype(dtype)]
         cfg.halo = int(halo)
         cfg.top_edge, cfg.bottom_edge = int(top_edge), int(bottom_edge)
+        cfg.lattice, self.Q = _LATTICES[lattice]
         h = ctypes.c_void_p()
         _check(self._L.lbm_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
@@ -226,7 +231,7 @@ class Solver:
 
     def upload_cells(self, cells, row0=0):
         c = np.ascontiguousarray(cells, dtype=np.float32)
-        assert c.ndim == 3 and c.shape[1] == self.M and c.shape[2] == 9, c.shape
+        assert c.ndim == 3 and c.shape[1] == self.M and c.shape[2] == self.Q, c.shape
         _check(self._L.lbm_upload_cells(self._h, _fptr(c), row0, c.shape[0]))
 
     def init_equilibrium(self, rho, u, amp=0.0, seed=0, row_offset=0, global_rows=0):
@@ -300,7 +305,7 @@ class Solver:
 
     def read_cells(self, rows=None, cols=None):
         r0, nr, c0, nc = self._window(rows, cols)
-        out = np.empty((nr, nc, 9), np.float32)
+        out = np.empty((nr, nc, self.Q), np.float32)
         _check(self._L.lbm_read_cells(self._h, _fptr(out), r0, nr, c0, nc))
         return out
 
