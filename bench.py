@@ -216,6 +216,23 @@ def main():
                 "finite": bool(np.isfinite(rho3).all() and np.isfinite(u3).all()),
                 "hbm_GBps_at_36B": g3 * 36, "frac_of_36B_roofline": g3 * 36 / HBM_PEAK_GBS,
                 "workload": f"{rows}x{cols} periodic, fp16 storage / fp32 compute, T=1"}
+        # SURVEY.md 8(f4), scoped: the draft's D2Q21 lattice (latticeboltzmann.jl:3-22, its own
+        # parameters :27-29) on the same grid, one update per launch, 2 x 21 x 4 = 168 B per
+        # cell-update.  Parity-unpinned by the reference; reported beside the headline, never as `value`.
+        s5 = hk.Solver(rows, cols, 0.01, inner_timesteps=1, boundary="periodic", device=local_rank,
+                       lattice="d2q21")
+        s5.init_equilibrium(100.0, (0.0, 0.3), amp=0.01, seed=0)
+        s5.fused_collide_stream(3)
+        s5.sync()
+        n5 = max(SIDE_LAUNCHES, args.steps // 10)
+        ms5 = s5.fused_collide_stream_timed(n5)
+        u5, rho5 = s5.read_moments(rows=(0, 8), cols=(0, 64))
+        s5.close()
+        g5 = rows * cols * n5 / ms5 / 1e6
+        d2q21 = {"value": g5, "unit": "GLUPS", "launches": n5, "ms_per_launch": ms5 / n5,
+                 "finite": bool(np.isfinite(rho5).all() and np.isfinite(u5).all()),
+                 "hbm_GBps_at_168B": g5 * 168, "frac_of_168B_roofline": g5 * 168 / HBM_PEAK_GBS,
+                 "workload": f"{rows}x{cols} periodic, D2Q21 (latticeboltzmann.jl:3-22), OMEGA=0.01, u=[0,0.3], T=1"}
     else:
         slab = SlabSolver(rows * world, cols, OMEGA, rank, world, boundary="periodic",
                           halo=args.halo, device=local_rank, dist=dist, tb_max_depth=args.depth)
@@ -319,6 +336,7 @@ def main():
         if world == 1:
             line["temporal_blocking"] = tb
             line["fp16_storage"] = fp16
+            line["d2q21"] = d2q21
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -24,6 +24,14 @@ def main():
         sh = tuple(int(v) for v in z["yeet_shape"])
         yeet = np.unpackbits(z["yeet_bits"])[:sh[0] * sh[1]].reshape(sh)
         s.upload_blocked(np.tile(yeet, (-(-N // sh[0]), -(-M // sh[1])))[:N, :M])
+    if len(sys.argv) > 10 and sys.argv[10].startswith("stripes"):  # a blocked column every k columns: every wave sees an obstacle
+        k = int(sys.argv[10][7:] or 128)
+        b = np.zeros((N, M), np.uint8); b[:, ::k] = 1
+        s.upload_blocked(b)
+    if len(sys.argv) > 10 and sys.argv[10].startswith("dots"):  # one blocked cell every k columns and k rows
+        k = int(sys.argv[10][4:] or 128)
+        b = np.zeros((N, M), np.uint8); b[::k, ::k] = 1
+        s.upload_blocked(b)
     s.fused_collide_stream(3)
     s.sync()
     for rep in range(3):
