@@ -149,6 +149,48 @@ __global__ __launch_bounds__(64) void kt1(const float* __restrict__ gin, float* 
     }
 }
 
+// ROWS vertically adjacent tiles per wave (row-major layout only), the product's addressing: the same
+// 9 loads per tile, but one wave asks for the contiguous pieces that ROWS neighbouring rows share
+// (768 / 1536 / 2304 / ... bytes per source row instead of 768 each); all loads issued before any use.
+template <int ROWS>
+__global__ __launch_bounds__(64) void kt1r(const float* __restrict__ gin, float* __restrict__ gout, Lay L,
+                                           FastDiv by_p, Geom geo) {
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int lane = threadIdx.x;
+    int yr, xi;
+    fastdivmod(tile, by_p, yr, xi);
+    const int y0 = yr * ROWS;
+    const bool seam_m = xi == L.P - 1, seam_p = xi == 0;
+    const unsigned off0 = (unsigned)(xi * CHUNK + lane);
+    // P == Mb: the periodic wrap stays inside the row (block 0 / block P-1)
+    const unsigned offm_w = lane == 63 ? (seam_m ? 0u : (unsigned)((xi + 1) * CHUNK)) : off0 + 1;
+    const unsigned offp = lane == 0 ? (unsigned)(((seam_p ? L.P : xi) - 1) * CHUNK + 63) : off0 - 1;
+    float v[ROWS][Q];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int y = y0 + r;
+        const int yu = y == 0 ? L.N - 1 : y - 1, yd = y == L.N - 1 ? 0 : y + 1;
+        const float* rp[3] = {gin + (long long)yd * L.S * CHUNK, gin + (long long)y * L.S * CHUNK, gin + (long long)yu * L.S * CHUNK};
+#pragma unroll
+        for (int k = 0; k < Q; k++) {
+            const int dy = dy_of(k), dx = dx_of(k), sl = slot_of(k) * LANES;
+            const unsigned off = dx == 0 ? off0 : (dx == 1 ? offp : offm_w);
+            v[r][k] = __builtin_nontemporal_load(reinterpret_cast<const float*>(
+                reinterpret_cast<const char*>(rp[dy + 1] + sl) + (size_t)(off * 4u)));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+        for (int k = 0; k < Q; k++) asm("" : "+v"(v[r][k]));
+        collide_to(v[r], false, 0ull, omega_of(geo), [&](const float* out) {
+            float* o = gout + ((long long)(y0 + r) * L.S + xi) * CHUNK + lane;
+#pragma unroll
+            for (int k = 0; k < Q; k++) __builtin_nontemporal_store(out[k], o + slot_of(k) * LANES);
+        });
+    }
+}
+
 // value of (y, x, slot), independent of the layout
 __global__ void initk(float* f, Lay L) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // over N * Mb * 576 logical elements
@@ -177,7 +219,7 @@ __global__ void sumk(const float* f, Lay L, unsigned long long* acc) {
 }
 
 typedef void (*Kfn)(const float*, float*, Lay, FastDiv, Geom);
-struct Var { const char* name; Kfn fn; int P; bool inplace; bool real; double bytes; int pad; };
+struct Var { const char* name; Kfn fn; int P; bool inplace; bool real; double bytes; int pad; int rows = 1; unsigned lds = 0; };
 
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 16384, M = argc > 2 ? atoi(argv[2]) : 16384;
@@ -209,6 +251,19 @@ int main(int argc, char** argv) {
         vars.push_back({nm, kt1<K_STEP2, false>, Mb, false, true, step_bytes, pad});
     }
     if (Mb % 32 == 0 && Mb > 32) vars.push_back({"step2 panels P=32 pad=1", kt1<K_STEP2, false>, 32, false, true, step_bytes, 1});
+    if (getenv("KT1_ROWS")) {
+        vars.resize(1);
+        vars.push_back({"step2 row-major", kt1<K_STEP2, false>, Mb, false, true, step_bytes});
+        for (unsigned l : {9u << 10, 12u << 10, 18u << 10, 26u << 10}) {
+            char* nm = new char[64]; snprintf(nm, 64, "2 rows/wave lds=%u", l);
+            vars.push_back({nm, kt1r<2>, Mb, false, true, step_bytes, 0, 2, l});
+        }
+        for (unsigned l : {18u << 10, 26u << 10, 36u << 10, 53u << 10}) {
+            char* nm = new char[64]; snprintf(nm, 64, "4 rows/wave lds=%u", l);
+            vars.push_back({nm, kt1r<4>, Mb, false, true, step_bytes, 0, 4, l});
+        }
+    }
+    if (!getenv("KT1_ROWS")) {
     vars.push_back({"copy chunk 2buf", kt1<K_COPY, false>, Mb, false, false, step_bytes});
     vars.push_back({"copy chunk inplace", kt1<K_COPY, true>, Mb, true, false, step_bytes});
     vars.push_back({"copy 3rows 2buf", kt1<K_COPY3, false>, Mb, false, false, step_bytes});
@@ -219,6 +274,7 @@ int main(int argc, char** argv) {
     vars.push_back({"copy chunk shifted -> 3rows", kt1<K_COPY3WS, false>, Mb, false, false, step_bytes});
     vars.push_back({"copy 3rows 2buf P=16", kt1<K_COPY3, false>, 16, false, false, step_bytes});
     vars.push_back({"copy 3rows inplace P=16", kt1<K_COPY3, true>, 16, true, false, step_bytes});
+    }
 
     auto lay_of = [&](int P, int pad) {
         // a last panel narrower than P is not supported here: P = 23 pads Mb up in the benchmark only
@@ -239,7 +295,7 @@ int main(int argc, char** argv) {
                 hipLaunchKernelGGL(initk, dim3((unsigned)(((long long)N * Mb * CHUNK + 255) / 256)), dim3(256), 0, 0, a, L);
             if (r == 0 && V.real) {  // correctness: one update from the same logical state
                 hipLaunchKernelGGL(initk, dim3((unsigned)(((long long)N * Mb * CHUNK + 255) / 256)), dim3(256), 0, 0, a, L);
-                hipLaunchKernelGGL(V.fn, dim3(ntiles), dim3(64), lds, 0, (const float*)a, b, L, by_p, geo);
+                hipLaunchKernelGGL(V.fn, dim3(ntiles / V.rows), dim3(64), V.lds ? V.lds : lds, 0, (const float*)a, b, L, by_p, geo);
                 CHECK(hipMemset(acc, 0, 8));
                 hipLaunchKernelGGL(sumk, dim3((unsigned)(((long long)N * Mb * CHUNK + 255) / 256)), dim3(256), 0, 0, (const float*)b, L, acc);
                 unsigned long long s = 0; CHECK(hipMemcpy(&s, acc, 8, hipMemcpyDeviceToHost));
@@ -248,7 +304,7 @@ int main(int argc, char** argv) {
             }
             CHECK(hipEventRecord(e0, 0));
             for (int i = 0; i < reps; i++) {
-                hipLaunchKernelGGL(V.fn, dim3(ntiles), dim3(64), lds, 0, (const float*)a, b, L, by_p, geo);
+                hipLaunchKernelGGL(V.fn, dim3(ntiles / V.rows), dim3(64), V.lds ? V.lds : lds, 0, (const float*)a, b, L, by_p, geo);
                 if (!V.inplace) std::swap(a, b);
             }
             CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
