@@ -30,7 +30,7 @@ __device__ __forceinline__ long long chunk_off(const Lay& L, int y, int xb) {
     return (long long)pn * L.panelStride + ((long long)y * L.S + xi) * CHUNK;
 }
 
-enum { K_STEP = 0, K_COPY = 1, K_COPY3 = 2, K_COPY3S = 3, K_STEP2 = 4, K_COPY3W = 5, K_COPY3WS = 6 };  // 3W: read the own chunk, WRITE the three 768-byte pieces to rows y-1, y, y+1 (push in y); 3WS: the same with lane-shifted loads (pull in x)
+enum { K_STEP = 0, K_COPY = 1, K_COPY3 = 2, K_COPY3S = 3, K_STEP2 = 4, K_COPY3W = 5, K_COPY3WS = 6, K_WR1 = 7, K_WR4 = 8, K_COPYW4 = 9 };  // 3W: read the own chunk, WRITE the three 768-byte pieces to rows y-1, y, y+1 (push in y); 3WS: the same with lane-shifted loads (pull in x)
 // INPLACE: the destination is the source location(s); for K_COPY3* that means the three 768-byte
 // pieces go back where they came from (rows y-1, y, y+1), as an AA-pattern odd step would write.
 template <int KIND, bool INPLACE>
@@ -92,6 +92,35 @@ __global__ __launch_bounds__(64) void kt1(const float* __restrict__ gin, float* 
     const long long om[3] = {chunk_off(L, yd, xbm), chunk_off(L, y, xbm), chunk_off(L, yu, xbm)};
     const long long op[3] = {chunk_off(L, yd, xbp), chunk_off(L, y, xbp), chunk_off(L, yu, xbp)};
     float a[Q];
+    if (KIND == K_WR1 || KIND == K_WR4 || KIND == K_COPYW4) {
+        // write-only chunk: nine dword stores per wave (K_WR1) against two dwordx4 + one dword store
+        // (K_WR4: the same 2304 bytes); K_COPYW4: copy a chunk, dword loads, transposed through LDS,
+        // stored as two dwordx4 + one dword
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        float* o = gout + o0[1];
+        if (KIND == K_WR1) {
+#pragma unroll
+            for (int k = 0; k < Q; k++) __builtin_nontemporal_store((float)(tile + k), o + 64 * k + lane);
+        } else if (KIND == K_WR4) {
+            const v4 v = {(float)tile, 1.0f, 2.0f, (float)lane};
+            __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o) + lane);
+            __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o) + 64 + lane);
+            __builtin_nontemporal_store((float)tile, o + 512 + lane);
+        } else {
+            __shared__ float t[512];
+            const float* p = gin + o0[1] + lane;
+#pragma unroll
+            for (int k = 0; k < Q; k++) a[k] = __builtin_nontemporal_load(p + 64 * k) + 1.0f;
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[64 * k + lane] = a[k];
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): one wave reads what it wrote itself
+            const v4 w0 = reinterpret_cast<const v4*>(t)[lane], w1 = reinterpret_cast<const v4*>(t)[64 + lane];
+            __builtin_nontemporal_store(w0, reinterpret_cast<v4*>(o) + lane);
+            __builtin_nontemporal_store(w1, reinterpret_cast<v4*>(o) + 64 + lane);
+            __builtin_nontemporal_store(a[8], o + 512 + lane);
+        }
+        return;
+    }
     if (KIND == K_COPY) {
         const float* p = gin + o0[1] + lane;
 #pragma unroll
@@ -251,6 +280,13 @@ int main(int argc, char** argv) {
         vars.push_back({nm, kt1<K_STEP2, false>, Mb, false, true, step_bytes, pad});
     }
     if (Mb % 32 == 0 && Mb > 32) vars.push_back({"step2 panels P=32 pad=1", kt1<K_STEP2, false>, 32, false, true, step_bytes, 1});
+    if (getenv("KT1_WIDE")) {
+        vars.resize(1);
+        vars.push_back({"copy chunk 2buf", kt1<K_COPY, false>, Mb, false, false, step_bytes});
+        vars.push_back({"copy chunk, LDS transpose, 2x dwordx4 + dword stores", kt1<K_COPYW4, false>, Mb, false, false, step_bytes});
+        vars.push_back({"write-only chunk, 9 dword stores", kt1<K_WR1, false>, Mb, false, false, step_bytes / 2});
+        vars.push_back({"write-only chunk, 2x dwordx4 + dword", kt1<K_WR4, false>, Mb, false, false, step_bytes / 2});
+    } else
     if (getenv("KT1_ROWS")) {
         vars.resize(1);
         vars.push_back({"step2 row-major", kt1<K_STEP2, false>, Mb, false, true, step_bytes});
@@ -263,7 +299,7 @@ int main(int argc, char** argv) {
             vars.push_back({nm, kt1r<4>, Mb, false, true, step_bytes, 0, 4, l});
         }
     }
-    if (!getenv("KT1_ROWS")) {
+    if (!getenv("KT1_ROWS") && !getenv("KT1_WIDE")) {
     vars.push_back({"copy chunk 2buf", kt1<K_COPY, false>, Mb, false, false, step_bytes});
     vars.push_back({"copy chunk inplace", kt1<K_COPY, true>, Mb, true, false, step_bytes});
     vars.push_back({"copy 3rows 2buf", kt1<K_COPY3, false>, Mb, false, false, step_bytes});
