@@ -43,7 +43,7 @@
 #define LBM_TB_CPL2 2
 #endif
 #ifndef LBM_TB_NB3
-#define LBM_TB_NB3 8
+#define LBM_TB_NB3 10  // round 3: 218.4 against 214.5 GLUPS with NB = 8 (158 KB of LDS, 15 waves; NB = 6: 209.5)
 #define LBM_TB_CPL3 2
 #endif
 #ifndef LBM_TB_NB4
