@@ -71,8 +71,12 @@ typedef enum {
     LBM_LATTICE_D2Q9 = 0,  /* latticeboltzmann.py:24-35 */
     LBM_LATTICE_D2Q21 = 1  /* the draft's lattice, latticeboltzmann.jl:3-22 (r2 = 3/2, 21 weights and
                               velocities (dy, dx) with |d| <= 3; opposite of k is 20-k).  Scoped: one
-                              update per launch, LBM_BOUNDARY_PERIODIC, LBM_STORE_F32, single domain.
-                              cells are float32 (N, M, 21); N, M >= 4.  Supported calls: create /
+                              update per launch, LBM_BOUNDARY_PERIODIC or LBM_BOUNDARY_REFERENCE (the
+                              slices of latticeboltzmann.py:115-120 with these velocities: the first
+                              dx columns / dy rows take surroundings[k], the last |dx| / |dy| keep
+                              their own value), LBM_STORE_F32, single domain.  cells are float32
+                              (N, M, 21) and lbm_set_surroundings takes 21 values; N, M >= 4.
+                              Supported calls: create / set_surroundings /
                               destroy / set_stream, upload_blocked / upload_cells / read_blocked,
                               init_equilibrium (row_offset / global_rows ignored), init_blocked_discs,
                               fused_collide_stream[_timed], advance, sync, steps_done, read_cells,
@@ -137,7 +141,7 @@ int lbm_set_stream(lbm_solver* s, void* hip_stream);
  * solver-local coordinates; ghost rows are addressed as -halo..-1 and N..N+halo-1.  Before the
  * first step cells may be uploaded in pieces; once the solver has stepped, an upload is a new
  * initial condition and must cover all N rows (it resets the step count). -------------------- */
-int lbm_set_surroundings(lbm_solver* s, const float surroundings[9]);
+int lbm_set_surroundings(lbm_solver* s, const float* surroundings /* 9 values; 21 for LBM_LATTICE_D2Q21 */);
 int lbm_upload_blocked(lbm_solver* s, const uint8_t* blocked, int row0, int nrows);
 int lbm_upload_cells(lbm_solver* s, const float* cells, int row0, int nrows);
 /* Device-side initial condition for grids too large to stage through the host: every cell

@@ -36,7 +36,8 @@ struct lbm_solver {
     lbm_config cfg;
     Geom geo;
     int xmode;
-    bool q21;     // LBM_LATTICE_D2Q21 (lbm_d2q21.hip): periodic, fp32, one update per launch
+    bool q21;     // LBM_LATTICE_D2Q21 (lbm_d2q21.hip): fp32, one update per launch
+    float surr21[Q21];  // its surroundings (reference edges)
     int Q;        // populations per cell: 9 or 21
     bool half;
     int T;
@@ -180,9 +181,9 @@ int lbm_create(const lbm_config* cfg, lbm_solver** out) {
     if (cfg->lattice != LBM_LATTICE_D2Q9 && cfg->lattice != LBM_LATTICE_D2Q21)
         return fail(LBM_ERR_INVALID, "unknown lattice %d", cfg->lattice);
     if (cfg->lattice == LBM_LATTICE_D2Q21) {
-        if (cfg->boundary != LBM_BOUNDARY_PERIODIC || cfg->storage != LBM_STORE_F32 || cfg->halo != 0 ||
+        if (cfg->boundary == LBM_BOUNDARY_CUDA_KERNEL || cfg->storage != LBM_STORE_F32 || cfg->halo != 0 ||
             cfg->top_edge != LBM_YEDGE_DOMAIN || cfg->bottom_edge != LBM_YEDGE_DOMAIN)
-            return fail(LBM_ERR_UNSUPPORTED, "LBM_LATTICE_D2Q21 is periodic, fp32, single-domain only");
+            return fail(LBM_ERR_UNSUPPORTED, "LBM_LATTICE_D2Q21 is periodic or reference edges, fp32, single-domain only");
         if (cfg->N < 4 || cfg->M < 4) return fail(LBM_ERR_INVALID, "LBM_LATTICE_D2Q21 needs N >= 4 and M >= 4");
     }
     const bool st = cfg->top_edge == LBM_YEDGE_SEAM, sb = cfg->bottom_edge == LBM_YEDGE_SEAM;
@@ -279,9 +280,13 @@ int lbm_set_stream(lbm_solver* s, void* hip_stream) {
     return LBM_OK;
 }
 
-int lbm_set_surroundings(lbm_solver* s, const float surroundings[9]) {
+int lbm_set_surroundings(lbm_solver* s, const float* surroundings) {
     ENTER(s);
     if (!surroundings) return fail(LBM_ERR_INVALID, "surroundings is null");
+    if (s->q21) {  // 21 values for this lattice
+        memcpy(s->surr21, surroundings, Q21 * sizeof(float));
+        return LBM_OK;
+    }
     memcpy(s->geo.surr, surroundings, 9 * sizeof(float));
     return LBM_OK;
 }
@@ -410,7 +415,7 @@ static int advance(lbm_solver* s, long long total, int max_depth) {
             HIPCHK(launch_q21_collide(s->buf[s->cur], s->mask, g, s->stream));
             s->pulled = true;
         } else {
-            HIPCHK(launch_q21_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->stream));
+            HIPCHK(launch_q21_step(s->buf[s->cur], s->buf[s->cur ^ 1], s->mask, g, s->xmode, s->surr21, s->stream));
             s->cur ^= 1;
         }
         s->steps++;
@@ -622,8 +627,8 @@ static int observe(lbm_solver* s, int row0, int nrows, int col0, int ncols, floa
         if (u) { du = (float*)p; p += cells_n * 8; }
         if (rgb) { dg = (uint8_t*)p; }
         if (s->q21)
-            HIPCHK(launch_q21_observe(s->buf[s->cur], s->mask, s->geo, s->pulled, row0 + r, n, col0, ncols, dc, dr,
-                                      du, s->stream));
+            HIPCHK(launch_q21_observe(s->buf[s->cur], s->mask, s->geo, s->xmode, s->surr21, s->pulled, row0 + r, n, col0,
+                                      ncols, dc, dr, du, s->stream));
         else
         HIPCHK(launch_observe(s->buf[s->cur], s->mask, s->geo, s->xmode, s->half, s->pulled, row0 + r, n,
                               col0, ncols, dc, dr, du, dg, s->stream));

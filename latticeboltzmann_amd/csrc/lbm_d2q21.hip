@@ -1,5 +1,5 @@
 // D2Q21 (scoped): the lattice of the reference's draft latticeboltzmann.jl:3-22 as a
-// second compile-time lattice for the ONE-update kernel.  Periodic boundary, fp32 storage, single
+// second compile-time lattice for the ONE-update kernel.  Periodic or reference edges, fp32 storage, single
 // domain, no LDS temporal blocking, no rendering.  PARITY UNPINNED by the reference (the draft is not
 // a runnable program; only its weight and velocity tables and their four asserts are pins); the
 // semantics are those of oracle/lbm_d2q21.py, which the kernels reproduce bit for bit.
@@ -44,34 +44,80 @@ __device__ __forceinline__ float w_of(int k) {
     return t[k];
 }
 
-// --- pull, periodic ------------------------------------------------------------------------------
-__device__ __forceinline__ void pull(const float* __restrict__ g, const Geom& geo, int y, int xb, int lane,
-                                     float t[Q]) {
+struct Surr { float v[Q]; };  // surroundings, reference k order (lbm_set_surroundings)
+
+// --- pull ----------------------------------------------------------------------------------------
+// t[k] = g_k(y - dy, x - dx).  Periodic: wrapped.  Reference (latticeboltzmann.py:115-120 with this
+// lattice's velocities, which reach up to three cells): where that source is outside the domain,
+// surroundings[k] if (dx > 0 and x < dx) or (dy > 0 and y < dy), else the cell's OWN g_k(y, x) (the
+// reference's empty negative slices: the last |dx| columns / |dy| rows keep their value).  Only
+// waves within three cells of an edge pay for the rule (EDGE, wave-uniform).
+template <int XMODE, bool EDGE>
+__device__ __forceinline__ void pull_impl(const float* __restrict__ g, const Geom& geo, const Surr& su, int y,
+                                          int xb, int lane, float t[Q]) {
     const int N = geo.N, M = geo.M;
     int x = xb * LANES + lane;
     x = x < M ? x : M - 1;
     unsigned off[7];  // element offset of source column x - dx inside a row, dx = -3 .. 3 (index dx + 3)
+    bool cob[7];      // that column does not exist (reference edges)
 #pragma unroll
     for (int d = -3; d <= 3; d++) {
         int xs = x - d;
-        xs = xs < 0 ? xs + M : xs;  // M >= 4 (checked by the API)
-        xs = xs >= M ? xs - M : xs;
+        cob[d + 3] = false;
+        if (XMODE == XMODE_PERIODIC) {
+            xs = xs < 0 ? xs + M : xs;  // M >= 4 (checked by the API)
+            xs = xs >= M ? xs - M : xs;
+        } else if (EDGE) {
+            cob[d + 3] = xs < 0 || xs >= M;
+            xs = cob[d + 3] ? x : xs;
+        }
         off[d + 3] = (unsigned)((xs >> 6) * CH + (xs & 63));
     }
     const float* rb[7];  // wave-uniform base of source row y - dy, dy = -3 .. 3
+    bool rob[7];
 #pragma unroll
     for (int d = -3; d <= 3; d++) {
         int ys = y - d;
-        ys = ys < 0 ? ys + N : ys;
-        ys = ys >= N ? ys - N : ys;
+        rob[d + 3] = false;
+        if (XMODE == XMODE_PERIODIC) {
+            ys = ys < 0 ? ys + N : ys;
+            ys = ys >= N ? ys - N : ys;
+        } else if (EDGE) {
+            rob[d + 3] = ys < 0 || ys >= N;
+            ys = rob[d + 3] ? y : ys;
+        }
         rb[d + 3] = g + (long long)ys * geo.rowStride;
     }
 #pragma unroll
     for (int k = 0; k < Q; k++) {
+        const int dy = dy_of(k), dx = dx_of(k);
         const float* p = reinterpret_cast<const float*>(
-            reinterpret_cast<const char*>(rb[dy_of(k) + 3] + slot_of(k) * LANES) + (size_t)(off[dx_of(k) + 3] * 4u));
-        t[k] = __builtin_nontemporal_load(p);
+            reinterpret_cast<const char*>(rb[dy + 3] + slot_of(k) * LANES) + (size_t)(off[dx + 3] * 4u));
+        if (XMODE != XMODE_PERIODIC && EDGE) {
+            // own value = own row AND own column, whichever of the two was missing
+            const float* own = reinterpret_cast<const float*>(
+                reinterpret_cast<const char*>(rb[3] + slot_of(k) * LANES) + (size_t)(off[3] * 4u));
+            p = (rob[dy + 3] || cob[dx + 3]) ? own : p;
+            const float v = *p;
+            const bool inlet = (dx > 0 && x < dx) || (dy > 0 && y < dy);
+            t[k] = inlet ? su.v[k] : v;
+        } else {
+            t[k] = __builtin_nontemporal_load(p);
+        }
     }
+}
+template <int XMODE>
+__device__ __forceinline__ void pull(const float* __restrict__ g, const Geom& geo, const Surr& su, int y, int xb,
+                                     int lane, float t[Q]) {
+    if (XMODE != XMODE_PERIODIC) {
+        const int x = xb * LANES + lane;
+        const bool edge = y < 3 || y >= geo.N - 3 || wave_any(x < 3 || x >= geo.M - 3);
+        if (edge) {
+            pull_impl<XMODE, true>(g, geo, su, y, xb, lane, t);
+            return;
+        }
+    }
+    pull_impl<XMODE, false>(g, geo, su, y, xb, lane, t);
 }
 
 __device__ __forceinline__ void reflect(float t[Q], bool blocked) {
@@ -133,15 +179,17 @@ __device__ __forceinline__ void collide(float a[Q], bool blocked, double omega) 
 }
 
 // --- kernels -------------------------------------------------------------------------------------
+template <int XMODE>
 __global__ __launch_bounds__(64) void step_kernel(const float* __restrict__ gin, float* __restrict__ gout,
-                                                  const uint64_t* __restrict__ mask, Geom geo, FastDiv by_mb) {
+                                                  const uint64_t* __restrict__ mask, Geom geo, FastDiv by_mb,
+                                                  Surr su) {
     const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x;
     int y, xb;
     fastdivmod(tile, by_mb, y, xb);
     float a[Q];
     const bool blocked = (mask[(long long)y * geo.Mb + xb] >> lane) & 1ull;
-    pull(gin, geo, y, xb, lane, a);
+    pull<XMODE>(gin, geo, su, y, xb, lane, a);
     reflect(a, blocked);
     collide(a, blocked, geo.omega);
     if (xb * LANES + lane < geo.M) {
@@ -170,11 +218,11 @@ __global__ __launch_bounds__(256) void collide_kernel(float* __restrict__ f, con
 }
 
 // numpy-visible state f over a window (see observe_kernel in lbm_kernels.hip)
-template <bool PULLED>
+template <int XMODE, bool PULLED>
 __global__ __launch_bounds__(256) void observe_kernel(const float* __restrict__ g, const uint64_t* __restrict__ mask,
                                                       Geom geo, int row0, int nrows, int col0, int ncols,
                                                       float* __restrict__ cells, float* __restrict__ rho,
-                                                      float* __restrict__ u) {
+                                                      float* __restrict__ u, Surr su) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int xb0 = col0 >> 6;
@@ -186,7 +234,7 @@ __global__ __launch_bounds__(256) void observe_kernel(const float* __restrict__ 
     float a[Q];
     if (PULLED) {
         const bool blocked = (mask[(long long)y * geo.Mb + xb] >> lane) & 1ull;
-        pull(g, geo, y, xb, lane, a);
+        pull<XMODE>(g, geo, su, y, xb, lane, a);
         reflect(a, blocked);
     } else {
         const int xc = x < geo.M ? x : geo.M - 1;
@@ -256,7 +304,14 @@ __global__ __launch_bounds__(256) void init_equilibrium_kernel(float* __restrict
 // --- launchers -----------------------------------------------------------------------------------
 static inline unsigned q21_wgs(long long tiles) { return (unsigned)((tiles + 3) / 4); }
 
-hipError_t launch_q21_step(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, hipStream_t st) {
+static q21::Surr surr_of(const float* surr21) {
+    q21::Surr su;
+    for (int k = 0; k < q21::Q; k++) su.v[k] = surr21[k];
+    return su;
+}
+
+hipError_t launch_q21_step(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
+                           const float* surr21, hipStream_t st) {
     const long long tiles = (long long)geo.N * geo.Mb;
     if (tiles <= 0) return hipSuccess;
     if (tiles >= (1ll << 26)) return hipErrorInvalidValue;  // 2^32 threads per launch (4.3e9 cells = 360 GB: cannot exist)
@@ -266,8 +321,12 @@ hipError_t launch_q21_step(const void* gin, void* gout, const uint64_t* mask, co
         const char* e = getenv("LBM_Q21_LDS_CAP");
         return e ? (unsigned)atoi(e) : 18u << 10;
     }();
-    hipLaunchKernelGGL(q21::step_kernel, dim3((unsigned)tiles), dim3(64), lds, st, (const float*)gin, (float*)gout,
-                       mask, geo, make_fastdiv(geo.Mb));
+    if (xmode == XMODE_PERIODIC)
+        hipLaunchKernelGGL(q21::step_kernel<XMODE_PERIODIC>, dim3((unsigned)tiles), dim3(64), lds, st, (const float*)gin,
+                           (float*)gout, mask, geo, make_fastdiv(geo.Mb), surr_of(surr21));
+    else
+        hipLaunchKernelGGL(q21::step_kernel<XMODE_REFERENCE>, dim3((unsigned)tiles), dim3(64), lds, st, (const float*)gin,
+                           (float*)gout, mask, geo, make_fastdiv(geo.Mb), surr_of(surr21));
     return hipGetLastError();
 }
 
@@ -277,17 +336,19 @@ hipError_t launch_q21_collide(void* f, const uint64_t* mask, const Geom& geo, hi
     return hipGetLastError();
 }
 
-hipError_t launch_q21_observe(const void* g, const uint64_t* mask, const Geom& geo, bool pulled, int row0, int nrows,
-                              int col0, int ncols, float* cells, float* rho, float* u, hipStream_t st) {
+hipError_t launch_q21_observe(const void* g, const uint64_t* mask, const Geom& geo, int xmode, const float* surr21,
+                              bool pulled, int row0, int nrows, int col0, int ncols, float* cells, float* rho,
+                              float* u, hipStream_t st) {
     if (nrows <= 0 || ncols <= 0) return hipSuccess;
     const int nxb = ((col0 + ncols + 63) >> 6) - (col0 >> 6);
     const unsigned nwg = q21_wgs((long long)nrows * nxb);
-    if (pulled)
-        hipLaunchKernelGGL(q21::observe_kernel<true>, dim3(nwg), dim3(256), 0, st, (const float*)g, mask, geo, row0,
-                           nrows, col0, ncols, cells, rho, u);
-    else
-        hipLaunchKernelGGL(q21::observe_kernel<false>, dim3(nwg), dim3(256), 0, st, (const float*)g, mask, geo, row0,
-                           nrows, col0, ncols, cells, rho, u);
+    const q21::Surr su = surr_of(surr21);
+#define Q21_OBS(XM, PU)                                                                                            \
+    hipLaunchKernelGGL((q21::observe_kernel<XM, PU>), dim3(nwg), dim3(256), 0, st, (const float*)g, mask, geo, row0, \
+                       nrows, col0, ncols, cells, rho, u, su)
+    if (xmode == XMODE_PERIODIC) { if (pulled) Q21_OBS(XMODE_PERIODIC, true); else Q21_OBS(XMODE_PERIODIC, false); }
+    else { if (pulled) Q21_OBS(XMODE_REFERENCE, true); else Q21_OBS(XMODE_REFERENCE, false); }
+#undef Q21_OBS
     return hipGetLastError();
 }
 

@@ -28,12 +28,14 @@ hipError_t launch_init_equilibrium(void* f, const Geom& geo, bool half, float rh
 hipError_t launch_init_discs(uint64_t* mask, const Geom& geo, int ndiscs, int radius, uint64_t seed,
                              long long row_offset, long long global_rows, hipStream_t st);
 
-// D2Q21 (lbm_d2q21.hip): 21 slots per chunk, periodic, fp32, one update per launch
+// D2Q21 (lbm_d2q21.hip): 21 slots per chunk, periodic or reference edges, fp32, one update per launch
 constexpr int Q21 = 21;
-hipError_t launch_q21_step(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, hipStream_t st);
+hipError_t launch_q21_step(const void* gin, void* gout, const uint64_t* mask, const Geom& geo, int xmode,
+                           const float* surr21, hipStream_t st);
 hipError_t launch_q21_collide(void* f, const uint64_t* mask, const Geom& geo, hipStream_t st);
-hipError_t launch_q21_observe(const void* g, const uint64_t* mask, const Geom& geo, bool pulled, int row0, int nrows,
-                              int col0, int ncols, float* cells, float* rho, float* u, hipStream_t st);
+hipError_t launch_q21_observe(const void* g, const uint64_t* mask, const Geom& geo, int xmode, const float* surr21,
+                              bool pulled, int row0, int nrows, int col0, int ncols, float* cells, float* rho,
+                              float* u, hipStream_t st);
 hipError_t launch_q21_import_cells(void* f, const Geom& geo, const float* cells, int row0, int nrows, hipStream_t st);
 hipError_t launch_q21_init_equilibrium(void* f, const Geom& geo, float rho, float u0, float u1, float amp,
                                        uint64_t seed, hipStream_t st);

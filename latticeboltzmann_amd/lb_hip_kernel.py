@@ -221,7 +221,7 @@ class Solver:
 
     # -- upload (drv.to_device, latticeboltzmann.py:147-150) --------------------------------------
     def set_surroundings(self, surroundings):
-        s = np.ascontiguousarray(surroundings, dtype=np.float32).reshape(9)
+        s = np.ascontiguousarray(surroundings, dtype=np.float32).reshape(self.Q)
         _check(self._L.lbm_set_surroundings(self._h, _fptr(s)))
 
     def upload_blocked(self, blocked, row0=0):

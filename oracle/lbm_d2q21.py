@@ -10,8 +10,8 @@ reference holds no output of it.  What it does pin, and tests/test_d2q21_cpu.py 
 Everything else is the reference's numpy algorithm (latticeboltzmann.py, as restated for D2Q9 in
 oracle/lbm_numpy.py) with those tables put in, which is what the draft's own body (:35-45, :58-75)
 spells: getEquilibrium with the general r2 (latticeboltzmann.py:87-89), moments (:180-183), collide
-with the float64 omega (:98, :107-113), stream (:115-120) in its periodic form (np.roll: the only
-boundary this lattice is built for), reflect (:122-123), order latticeboltzmann.jl:107-120.
+with the float64 omega (:98, :107-113), stream (:115-120: its slices verbatim, or np.roll for the
+periodic form), reflect (:122-123), order latticeboltzmann.jl:107-120.
 
 Two places where "numpy would decide" are decided here instead, because with velocity components
 of 2 and 3 the products are no longer exact and BLAS does not define its summation order or its use
@@ -123,6 +123,18 @@ def collide(cells, u, p, omega):
         cells += equilibrium
 
 
+def stream(cells, surroundings):
+    """latticeboltzmann.py:115-120, verbatim, with this lattice's velocities (up to three cells): the
+    first dx columns / dy rows take surroundings[k] for dx, dy > 0; the slices for dx, dy < 0
+    (`-2:0`, `-3:0`, ...) are empty, so the last |dx| columns / |dy| rows keep their own value."""
+    N, M = cells.shape[:2]
+    for k, (dy, dx) in enumerate(e):
+        cells[max(dy, 0):N + min(dy, 0), max(dx, 0):M + min(dx, 0), k] = \
+            cells[max(-dy, 0):N + min(-dy, 0), max(-dx, 0):M + min(-dx, 0), k]
+        cells[:, min(dx, 0):max(dx, 0), k] = surroundings[k]
+        cells[min(dy, 0):max(dy, 0), :, k] = surroundings[k]
+
+
 def stream_periodic(cells):
     for k, (dy, dx) in enumerate(e):
         cells[..., k] = np.roll(cells[..., k], (dy, dx), axis=(0, 1))
@@ -132,18 +144,30 @@ def reflect(cells, blocked):
     cells[blocked] = np.flip(cells[blocked], axis=-1)
 
 
-def step(cells, blocked, omega):
+def step(cells, blocked, omega, surroundings=None, boundary="periodic"):
     u, p = moments(cells)
     collide(cells, u, p, omega)
-    stream_periodic(cells)
+    if boundary == "periodic":
+        stream_periodic(cells)
+    else:
+        stream(cells, surroundings)
     reflect(cells, blocked)
 
 
-def run(cells, blocked, steps, omega_free=OMEGA):
+def run(cells, blocked, steps, omega_free=OMEGA, surroundings=None, boundary="periodic"):
     omega = make_omega(blocked, omega_free)
+    if boundary != "periodic" and surroundings is None:
+        surroundings = ambient()
     for _ in range(steps):
-        step(cells, blocked, omega)
+        step(cells, blocked, omega, surroundings, boundary)
     return cells
+
+
+def blocked_cylinder(N=400, M=800):
+    """latticeboltzmann.jl:30-32, 51: (x - N/2)^2 + (y - N/2)^2 <= (N/16)^2."""
+    def isBlocked(y, x):
+        return (x - N / 2) ** 2 + (y - N / 2) ** 2 <= (N / 16) ** 2
+    return np.fromfunction(isBlocked, (N, M))
 
 
 def perturbed_cells(N, M, seed=0, amp=0.01, p=p_ambient, u=u_ambient):

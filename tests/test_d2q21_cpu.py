@@ -66,3 +66,22 @@ def test_stream_moves_population_k_by_e_k():
     for k, (dy, dx) in enumerate(q.e):
         assert c[(4 + dy) % N, (5 + dx) % M, k] == k + 1
     assert np.count_nonzero(c) == 21
+
+
+def test_reference_stream_slices_reach_three_cells():
+    """latticeboltzmann.py:115-120 with velocities of up to three cells: the first dx columns / dy rows
+    take surroundings[k], the last |dx| / |dy| keep their own value (the empty `-3:0` slices)."""
+    N, M = 8, 9
+    surr = np.arange(100, 121, dtype=np.float32)
+    c = (np.arange(N * M * 21, dtype=np.float32).reshape(N, M, 21) + 1000)
+    want = c.copy()
+    for k, (dy, dx) in enumerate(q.e):
+        for y in range(N):
+            for x in range(M):
+                ys, xs = y - dy, x - dx
+                if (dx > 0 and x < dx) or (dy > 0 and y < dy):
+                    want[y, x, k] = surr[k]
+                elif 0 <= ys < N and 0 <= xs < M:
+                    want[y, x, k] = c[ys, xs, k]
+    q.stream(c, surr)
+    assert np.array_equal(c, want)

@@ -9,29 +9,32 @@ from oracle import lbm_d2q21 as q
 pytestmark = pytest.mark.gpu
 
 
-def _solver(N, M, omega, blocked, cells):
+def _solver(N, M, omega, blocked, cells, boundary="periodic", surr=None):
     from latticeboltzmann_amd.lb_hip_kernel import Solver
-    s = Solver(N, M, omega, boundary="periodic", lattice="d2q21")
+    s = Solver(N, M, omega, boundary=boundary, lattice="d2q21")
+    s.set_surroundings(q.ambient() if surr is None else surr)
     s.upload_blocked(blocked)
     s.upload_cells(cells)
     return s
 
 
-@pytest.mark.parametrize("shape", [(37, 130), (64, 64), (4, 4), (5, 67), (33, 200), (129, 7)])
+@pytest.mark.parametrize("boundary", ["periodic", "reference"])
+@pytest.mark.parametrize("shape", [(37, 130), (64, 64), (4, 4), (5, 67), (33, 200), (129, 7), (6, 128), (7, 129)])
 @pytest.mark.parametrize("omega", [q.OMEGA, 0.6, 1e-14])
-def test_d2q21_equals_its_oracle(shape, omega):
+def test_d2q21_equals_its_oracle(shape, omega, boundary):
     N, M = shape
     rng = np.random.default_rng(N * 1000 + M)
     blocked = rng.random((N, M)) < 0.08
     cells = q.perturbed_cells(N, M, seed=3, amp=0.05)
-    s = _solver(N, M, omega, blocked, cells)
+    surr = q.ambient(100, [0.02, 0.25])
+    s = _solver(N, M, omega, blocked, cells, boundary, surr)
     assert np.array_equal(s.read_blocked(), blocked)
     assert np.array_equal(s.read_cells(), cells)          # state right after upload
     ref = cells.copy()
     done = 0
     for n in (1, 1, 3, 12):
         s.fused_collide_stream(n)
-        q.run(ref, blocked, n, omega)
+        q.run(ref, blocked, n, omega, surr, boundary)
         done += n
         assert s.steps_done == done
         got = s.read_cells()
@@ -66,12 +69,29 @@ def test_d2q21_zero_density_and_device_initial_state():
     s.close()
 
 
+def test_d2q21_the_drafts_own_scene():
+    """latticeboltzmann.jl:25-32: the 400 x 800 cylinder, OMEGA = 0.01, rho = 100, u = [0, 0.3], inlet /
+    outflow edges, from the broadcast ambient state: 150 steps against the oracle, bit for bit."""
+    N, M = 400, 800
+    blocked = q.blocked_cylinder(N, M)
+    surr = q.ambient()
+    cells = np.ascontiguousarray(np.broadcast_to(surr, (N, M, 21)))
+    s = _solver(N, M, q.OMEGA, blocked, cells, "reference", surr)
+    s.fused_collide_stream(150)
+    ref = q.run(cells.copy(), blocked, 150, q.OMEGA, surr, "reference")
+    assert np.array_equal(s.read_cells(), ref)
+    u, rho = s.read_moments()
+    ur, rr = q.moments(ref)
+    assert np.array_equal(rho, rr) and np.array_equal(u, ur)
+    s.close()
+
+
 def test_d2q21_scope_is_enforced():
     from latticeboltzmann_amd.lb_hip_kernel import Solver
     import numpy as np
-    with pytest.raises(RuntimeError, match="periodic"):
-        Solver(16, 16, 0.3, boundary="reference", lattice="d2q21")
-    with pytest.raises(RuntimeError, match="periodic"):
+    with pytest.raises(RuntimeError, match="single-domain"):
+        Solver(16, 16, 0.3, boundary="cuda_kernel", lattice="d2q21")
+    with pytest.raises(RuntimeError, match="single-domain"):
         Solver(16, 16, 0.3, boundary="periodic", lattice="d2q21", dtype=np.float16)
     with pytest.raises(RuntimeError, match="N >= 4"):
         Solver(3, 16, 0.3, boundary="periodic", lattice="d2q21")

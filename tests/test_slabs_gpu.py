@@ -212,29 +212,31 @@ def test_advance_rows_checks_its_inputs():
     s.close()
 
 
-def test_bench_n2_rehearsal(tmp_path):
+@pytest.mark.parametrize("n,rows,cols", [(2, 2048, 2048), (8, 512, 1024)])
+def test_bench_n2_rehearsal(tmp_path, n, rows, cols):
     """bench.py's N > 1 branch (slab timing, the max-over-ranks all_reduce, the
     `slabs_temporal_blocking` side line) run end to end before the driver runs it on an 8-GPU
     node: a fresh child `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with
     two ranks sharing this box's one GPU, halos staged through the host over gloo
     (LBM_BENCH_BACKEND=gloo; RCCL refuses two ranks per device).  Checks the JSON contract, not
-    the speed."""
+    the speed.  n = 8 is the driver's largest case: a ring of eight slabs, eight processes on the one
+    GPU (the box allows 16)."""
     import json
     import subprocess
     env = dict(os.environ, LBM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "2048", "--cols", "2048",
+           os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--rows", str(rows), "--cols", str(cols),
            "--steps", "8", "--warmup", "4", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
-    (tmp_path / "bench_n2.log").write_text(r.stdout + "\n--- stderr ---\n" + r.stderr)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    (tmp_path / f"bench_n{n}.log").write_text(r.stdout + "\n--- stderr ---\n" + r.stderr)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["warmup"] == 4 and d["scaling"] == "weak"
+    assert d["n_gpus"] == n and d["steps"] == 8 and d["warmup"] == 4 and d["scaling"] == "weak"
     assert d["unit"] == "GLUPS" and d["value"] > 0 and d["higher_is_better"] is True
-    assert "gloo (rehearsal)" in d["config"]["decomposition"] and "2 y-slabs" in d["config"]["decomposition"]
+    assert "gloo (rehearsal)" in d["config"]["decomposition"] and f"{n} y-slabs" in d["config"]["decomposition"]
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
     tb = d["slabs_temporal_blocking"]
     assert "error" not in tb, tb

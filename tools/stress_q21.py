@@ -14,6 +14,8 @@ for i in range(cases):
     M = int(rng.choice([rng.integers(4, 70), rng.integers(60, 300)]))
     omega = float(rng.choice([1e-14, 0.01, 0.3, 0.6, 1.0, 1.7]))
     dens = float(rng.choice([0.0, 0.03, 0.2]))
+    boundary = str(rng.choice(["periodic", "reference"]))
+    surr = q.ambient(100, [rng.uniform(-0.05, 0.05), rng.uniform(-0.1, 0.3)])
     blocked = rng.random((N, M)) < dens
     cells = q.perturbed_cells(N, M, seed=int(rng.integers(1 << 30)), amp=0.05,
                               u=[rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.3)])
@@ -24,17 +26,18 @@ for i in range(cases):
         elif kind == 1: cells[y:y + 2, x:x + 3] = 0
         elif kind == 2: cells[y:y + 2, x:x + 3] *= np.float32(1e32)
         else: cells[y:y + 2, x:x + 3] *= np.float32(1e-33)
-    s = Solver(N, M, omega, boundary="periodic", lattice="d2q21")
+    s = Solver(N, M, omega, boundary=boundary, lattice="d2q21")
+    s.set_surroundings(surr)
     s.upload_blocked(blocked); s.upload_cells(cells)
     ref = cells.copy()
     for n in rng.integers(1, 8, size=int(rng.integers(1, 4))):
         s.fused_collide_stream(int(n))
         with np.errstate(all="ignore"):
-            q.run(ref, blocked, int(n), omega)
+            q.run(ref, blocked, int(n), omega, surr, boundary)
         got = s.read_cells()
         if not np.array_equal(got, ref, equal_nan=True):
             w = np.argwhere((got != ref) & ~(np.isnan(got) & np.isnan(ref)))
-            print(f"MISMATCH case {i}: N={N} M={M} omega={omega} dens={dens}: {len(w)} values, first {w[:3].tolist()}", flush=True)
+            print(f"MISMATCH case {i}: N={N} M={M} {boundary} omega={omega} dens={dens}: {len(w)} values, first {w[:3].tolist()}", flush=True)
             bad += 1
             break
     s.close()
