@@ -16,6 +16,7 @@ without an NVIDIA GPU), geometry is a run-time parameter, and density / velocity
     python -m latticeboltzmann_amd.latticeboltzmann scene.png [MI355X|MI355X_T1] [--steps N]
 """
 import math
+import os
 import sys
 import time
 from itertools import count
@@ -175,16 +176,35 @@ def stats_line(N, M, inner_timesteps, dt, curr_iter):
 
 
 def _open_video(path):
+    """The reference's writer (latticeboltzmann.py:45,166): frames shrunk by 8 with a cubic filter into
+    `<image>.mp4` at 60 fps.  That needs imageio(-ffmpeg) and cv2; without them (this image) the same
+    frames, shrunk by 8 with PIL's bicubic filter, are written as `<image>.frames/NNNNNNNN.png` (encode
+    with e.g. `ffmpeg -framerate 60 -i %08d.png out.mp4`); with neither, None (the caller saves .npy)."""
     try:
         import cv2
         import imageio
+        writer = imageio.get_writer(path + '.mp4', fps=60)  # latticeboltzmann.py:45
+
+        def append(frame, M, N):
+            writer.append_data(cv2.resize(frame, dsize=(M // 8, N // 8), interpolation=cv2.INTER_CUBIC))
+        append.close = writer.close
+        return append
+    except ImportError:
+        pass
+    try:
+        from PIL import Image
     except ImportError:
         return None
-    writer = imageio.get_writer(path + '.mp4', fps=60)  # latticeboltzmann.py:45
+    outdir = path + '.frames'
+    os.makedirs(outdir, exist_ok=True)
+    count_ = [0]
 
     def append(frame, M, N):
-        writer.append_data(cv2.resize(frame, dsize=(M // 8, N // 8), interpolation=cv2.INTER_CUBIC))
-    append.close = writer.close
+        img = Image.fromarray(frame)
+        img = img.resize((max(M // 8, 1), max(N // 8, 1)), Image.BICUBIC)
+        img.save(os.path.join(outdir, f"{count_[0]:08d}.png"))
+        count_[0] += 1
+    append.close = lambda: None
     return append
 
 

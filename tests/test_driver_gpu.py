@@ -53,4 +53,10 @@ def test_driver_main_loop(tmp_path, capsys):
     out = capsys.readouterr().out
     assert "(96, 200)" in out and "GLUPS" in out and "Done" in out
     frames = sorted(f for f in os.listdir(tmp_path) if f.endswith(".npy") or f.endswith(".mp4"))
+    pngdir = path + ".frames"
+    if os.path.isdir(pngdir):  # no imageio / cv2: PNG frames shrunk by 8 (bicubic), as the reference's mp4 frames are
+        frames += sorted(os.listdir(pngdir))
+        im = Image.open(os.path.join(pngdir, frames[-1]))
+        assert im.size == (200 // 8, 96 // 8) and im.mode == "RGB"
+        assert len(os.listdir(pngdir)) == 1001 // lb.OUTPUT_INTERVAL + 1
     assert frames, "no frame was written"
