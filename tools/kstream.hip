@@ -191,6 +191,60 @@ static int run_dyn(const char* name, const float* a, float* b, long long nchunks
     fflush(stdout);
     return 0;
 }
+// MARCH: long-lived waves that walk DOWN the rows of a 16384-column field like stage 1 of the LDS
+// kernel (a wave owns one 64-column block, R rows).  WHOLE = 0: per destination row the three
+// 768-byte pieces the pull takes from rows y+1, y, y-1 (each chunk is read in three visits, an iteration
+// apart); WHOLE = 1: one whole 2304-byte chunk of row y+1 per iteration (what a register history of two
+// rows would make of it).  Both store one chunk per iteration.
+template <int WHOLE>
+__global__ __launch_bounds__(256) void kmarchcopy(const float* __restrict__ in, float* __restrict__ out, int nrows,
+                                                  int R) {
+    const int lane = threadIdx.x & 63;
+    const int nb = 256;  // blocks per row
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int xb = (int)(w % nb), y0 = (int)(w / nb) * R;
+    const long long RS = (long long)nb * 576;
+    auto row = [&](int y) { y = y < 0 ? y + nrows : (y >= nrows ? y - nrows : y); return in + (long long)y * RS + (long long)xb * 576 + lane; };
+    float v[9];
+    for (int i = 0; i < R; i++) {
+        const int y = y0 + i;
+        if (WHOLE) {
+            const float* p = row(y + 1);
+#pragma unroll
+            for (int k = 0; k < 9; k++) v[k] = __builtin_nontemporal_load(p + 64 * k);
+        } else {
+            const float* pd = row(y + 1), *p0 = row(y), *pu = row(y - 1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                v[k] = __builtin_nontemporal_load(pd + 64 * k);
+                v[3 + k] = __builtin_nontemporal_load(p0 + 64 * (3 + k));
+                v[6 + k] = __builtin_nontemporal_load(pu + 64 * (6 + k));
+            }
+        }
+        float* o = out + (long long)y * RS + (long long)xb * 576 + lane;
+#pragma unroll
+        for (int k = 0; k < 9; k++) __builtin_nontemporal_store(v[k], o + 64 * k);
+    }
+}
+template <int WHOLE>
+static int run_march(const char* name, const float* a, float* b, int R, unsigned lds, int rounds) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int nrows = 16384;
+    const unsigned grid = (unsigned)(256 / 4 * (nrows / R));
+    std::vector<float> t;
+    for (int r = 0; r < rounds + 1; r++) {
+        CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < 5; i++) hipLaunchKernelGGL(kmarchcopy<WHOLE>, dim3(grid), dim3(256), lds, 0, a, b, nrows, R);
+        CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r) t.push_back(ms / 5);
+    }
+    std::sort(t.begin(), t.end());
+    printf("%-34s R=%4d (LDS %6u): %.3f ms  %.3f TB/s\n", name, R, lds, t[t.size() / 2],
+           2.0 * 16384 * 256 * 2304 / t[t.size() / 2] / 1e9);
+    fflush(stdout);
+    return 0;
+}
 static unsigned g_base = 0;
 template <int MODE, int PF, int IO = 0, int EXTRA = 0>
 static int run(const char* name, const float* a, float* b, long long nchunks, int wg_per_cu, unsigned lds, int rounds, int sync_every = 8) {
@@ -228,6 +282,14 @@ int main(int argc, char** argv) {
     if (argc > 2 && !strcmp(argv[2], "pmc")) {  // the two ends of the lifetime effect only (for rocprofv3 --pmc passes)
         run<SHORT, 0>("short", a, b, nchunks, 4, 36u << 10, rounds);
         run<SWEEP, 0>("long/sweep", a, b, nchunks, 4, 36u << 10, rounds);
+        return 0;
+    }
+    if (argc > 2 && !strcmp(argv[2], "march")) {  // three pieces from three rows against one whole chunk, marching waves
+        for (int R : {64, 256, 1024})
+            for (unsigned l : {36u << 10, 53u << 10}) {
+                run_march<0>("march, 3 pieces of 768 B", a, b, R, l, rounds);
+                run_march<1>("march, 1 whole chunk", a, b, R, l, rounds);
+            }
         return 0;
     }
     if (argc > 2 && !strcmp(argv[2], "dyn")) {  // queue-fed persistent waves against both ends
