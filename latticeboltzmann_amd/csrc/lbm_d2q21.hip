@@ -179,6 +179,18 @@ __device__ __forceinline__ void collide(float a[Q], bool blocked, double omega) 
 }
 
 // --- kernels -------------------------------------------------------------------------------------
+// a lane's 21 populations into its chunk (wave-uniform address): streaming stores as in the D2Q9 kernel
+// (st_stream, lbm_device.h); the chunk is 5376 bytes, beyond a store's immediate offset, hence two bases
+template <int K = 0>
+__device__ __forceinline__ void store_chunk(float* chunk, int lane, const float* v) {
+    if constexpr (K < Q) {
+        constexpr int off = slot_of(K) * LANES * (int)sizeof(float), upper = 16 * LANES * (int)sizeof(float);
+        if constexpr (off < upper) st_stream<off>(chunk, (unsigned)lane * 4u, v[K]);
+        else st_stream<off - upper>(chunk + 16 * LANES, (unsigned)lane * 4u, v[K]);
+        store_chunk<K + 1>(chunk, lane, v);
+    }
+}
+
 template <int XMODE>
 __global__ __launch_bounds__(64) void step_kernel(const float* __restrict__ gin, float* __restrict__ gout,
                                                   const uint64_t* __restrict__ mask, Geom geo, FastDiv by_mb,
@@ -192,11 +204,7 @@ __global__ __launch_bounds__(64) void step_kernel(const float* __restrict__ gin,
     pull<XMODE>(gin, geo, su, y, xb, lane, a);
     reflect(a, blocked);
     collide(a, blocked, geo.omega);
-    if (xb * LANES + lane < geo.M) {
-        float* o = gout + (long long)y * geo.rowStride + (long long)xb * CH + lane;
-#pragma unroll
-        for (int k = 0; k < Q; k++) __builtin_nontemporal_store(a[k], o + slot_of(k) * LANES);
-    }
+    if (xb * LANES + lane < geo.M) store_chunk(gout + (long long)y * geo.rowStride + (long long)xb * CH, lane, a);
 }
 
 __global__ __launch_bounds__(256) void collide_kernel(float* __restrict__ f, const uint64_t* __restrict__ mask,

@@ -124,6 +124,44 @@ __device__ __forceinline__ void st_nt(float* p, float v) { __builtin_nontemporal
 __device__ __forceinline__ void st_nt(__half* p, float v) {
     __builtin_nontemporal_store(__half_as_ushort(__float2half_rn(v)), reinterpret_cast<unsigned short*>(p));
 }
+// The stores of the new state: non-temporal AND agent scope (`nt sc1`).  With sc1 the L2 writes the
+// line through to memory as it arrives instead of keeping it dirty until something evicts it, so the
+// writes reach the DRAM in the order the sweep produces them.  Measured on the T = 1 kernel, same box,
+// 16384 x 16384 (gpurun_out/r3_ab_stpolicy.log): plain 84.2 GLUPS, sc0 84.2, nt 88.1 (what
+// __builtin_nontemporal_store gives), sc1 89.4, sc0 sc1 89.3, nt sc0 sc1 89.7, nt sc1 89.85 - the step
+// from 0.793 to 0.809 of the 8 TB/s peak.  hipcc has no builtin that sets both bits (an agent-scope
+// atomic store gives sc1 alone), hence the inline assembly; a store needs no s_waitcnt bookkeeping of
+// the compiler's (nothing reads it back in the kernel), and stronger scope than needed is always safe.
+// BYTE_OFF: the instruction's immediate offset (13 bits signed).
+#ifndef LBM_ST_POLICY
+#define LBM_ST_POLICY "nt sc1"
+#endif
+// ... to wave_base (wave-uniform: an SGPR pair) + lane_byte_off + BYTE_OFF
+template <int BYTE_OFF>
+__device__ __forceinline__ void st_stream(float* wave_base, unsigned lane_byte_off, float v) {
+    static_assert(BYTE_OFF >= 0 && BYTE_OFF < 4096, "immediate offset of a global store");
+    asm volatile("global_store_dword %0, %1, %2 offset:%3 " LBM_ST_POLICY
+                 :: "v"(lane_byte_off), "v"(v), "s"(wave_base), "n"(BYTE_OFF) : "memory");
+}
+template <int BYTE_OFF>
+__device__ __forceinline__ void st_stream(__half* wave_base, unsigned lane_byte_off, float v) {
+    static_assert(BYTE_OFF >= 0 && BYTE_OFF < 4096, "immediate offset of a global store");
+    const unsigned h = __half_as_ushort(__float2half_rn(v));
+    asm volatile("global_store_short %0, %1, %2 offset:%3 " LBM_ST_POLICY
+                 :: "v"(lane_byte_off), "v"(h), "s"(wave_base), "n"(BYTE_OFF) : "memory");
+}
+// ... to a per-lane address + BYTE_OFF
+template <int BYTE_OFF>
+__device__ __forceinline__ void st_stream(float* p, float v) {
+    static_assert(BYTE_OFF >= 0 && BYTE_OFF < 4096, "immediate offset of a global store");
+    asm volatile("global_store_dword %0, %1, off offset:%2 " LBM_ST_POLICY :: "v"(p), "v"(v), "n"(BYTE_OFF) : "memory");
+}
+template <int BYTE_OFF>
+__device__ __forceinline__ void st_stream(__half* p, float v) {
+    static_assert(BYTE_OFF >= 0 && BYTE_OFF < 4096, "immediate offset of a global store");
+    const unsigned h = __half_as_ushort(__float2half_rn(v));
+    asm volatile("global_store_short %0, %1, off offset:%2 " LBM_ST_POLICY :: "v"(p), "v"(h), "n"(BYTE_OFF) : "memory");
+}
 
 // --- pull-stream (latticeboltzmann.py:115-120 in pull form) ------------------------------------
 // t[k] = g_k(y - dy, x - dx); where that source is outside the domain:

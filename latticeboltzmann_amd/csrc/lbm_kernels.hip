@@ -18,6 +18,15 @@ namespace lbm {
 // stores that fill one contiguous 2304-byte chunk.  No LDS, no barrier: nothing is reused.
 // Algorithmic HBM bytes per cell-update: 36 read + 36 written (latticeboltzmann.py:176).
 // ---------------------------------------------------------------------------------------------
+// a lane's nine populations into its chunk (wave-uniform address), streaming stores (st_stream, lbm_device.h)
+template <int K = 0, typename T>
+__device__ __forceinline__ void store_chunk(T* chunk, int lane, const float* v) {
+    if constexpr (K < Q) {
+        st_stream<slot_of(K) * LANES * (int)sizeof(T)>(chunk, (unsigned)lane * (unsigned)sizeof(T), v[K]);
+        store_chunk<K + 1>(chunk, lane, v);
+    }
+}
+
 template <int XMODE, typename T>
 __global__ __launch_bounds__(64) void step_kernel(const T* __restrict__ gin, T* __restrict__ gout,
                                                    const uint64_t* __restrict__ mask, Geom geo,
@@ -49,20 +58,12 @@ __global__ __launch_bounds__(64) void step_kernel(const T* __restrict__ gin, T* 
         const lanemask bm = ballot(blocked);
         reflect(a, blocked);
         collide_to(a, blocked, bm, omega_of(geo), [&](const float* out) {
-            if (xb * LANES + lane < geo.M) {
-                T* o = gout + (long long)(y + geo.G) * geo.rowStride + (long long)xb * CHUNK + lane;
-#pragma unroll
-                for (int k = 0; k < Q; k++) st_nt(o + slot_of(k) * LANES, out[k]);
-            }
+            if (xb * LANES + lane < geo.M) store_chunk(gout + (long long)(y + geo.G) * geo.rowStride + (long long)xb * CHUNK, lane, out);
         });
         return;
     }
 
-    if (xb * LANES + lane < geo.M) {
-        T* o = gout + (long long)(y + geo.G) * geo.rowStride + (long long)xb * CHUNK + lane;
-#pragma unroll
-        for (int k = 0; k < Q; k++) st_nt(o + slot_of(k) * LANES, a[k]);
-    }
+    if (xb * LANES + lane < geo.M) store_chunk(gout + (long long)(y + geo.G) * geo.rowStride + (long long)xb * CHUNK, lane, a);
 }
 
 // f -> g = collide(f) in place over rows [row0, row0+nrows): the first half of the first update
