@@ -287,17 +287,22 @@ static inline unsigned tiles_to_wgs(long long tiles) { return (unsigned)((tiles 
 // a float4 streaming copy reaches).  The cap is imposed the portable way: an unused dynamic-LDS
 // request per workgroup.  Workgroups are ONE wave: a four-wave workgroup holds its LDS, i.e. its
 // place under the cap, until its last wave has finished, so fewer than sixteen waves are at work on
-// average; with single-wave workgroups the cap is exact (same-box: 87.1 -> 87.8 GLUPS; 17 per CU at
-// 9 KB each and 16 at 10 KB give the same, 13 at 12 KB 85.0, uncapped 80.5).
+// average; with single-wave workgroups the cap is exact (same-box: 87.1 -> 87.8 GLUPS).
+// LDS is handed out in 1280-byte granules, so the steps are 16 waves per CU (up to 10240 bytes each),
+// 14 (up to 11520), 12 (up to 12800).  Re-swept in round 3 with the `nt sc1` stores
+// (gpurun_out/r3_cap_sweep*.log, GLUPS): uncapped 83.7, 16 waves 89.8-89.9, 14 waves 90.7-90.8, 12 waves
+// 87.2 with the tiny-omega common path; with the general path (float64 omega product: OMEGA = 0.05,
+// obstacles) 16 waves 90.3, 14 waves 88.9 - more arithmetic per byte wants more waves.
 // fp16 storage has half the bytes per wave in flight and twice the arithmetic per byte: it wants
-// all 32 waves (uncapped 174.5 GLUPS with single-wave workgroups, 173.1 with four-wave ones).
-static unsigned step_lds_cap(bool half) {
+// all 32 waves (uncapped 177.6 GLUPS, 16 waves 118).
+static unsigned step_lds_cap(bool half, bool tiny_omega) {
     static const int env = [] {
         const char* e = getenv("LBM_T1_LDS_CAP");  // development override, bytes per workgroup
         return e ? atoi(e) : -1;
     }();
     if (env >= 0) return (unsigned)env;
-    return half ? 0u : 9u << 10;
+    if (half) return 0u;
+    return tiny_omega ? 11u << 10 : 10u << 10;
 }
 
 template <typename T>
@@ -318,7 +323,7 @@ static hipError_t launch_step_t(const T* gin, T* gout, const uint64_t* mask, con
         return hipSuccess;
     }
     const unsigned nwg = (unsigned)((long long)nrows * geo.Mb);  // one single-wave workgroup per tile
-    const unsigned lds = step_lds_cap(sizeof(T) == 2);
+    const unsigned lds = step_lds_cap(sizeof(T) == 2, geo.omega_tiny != 0);
     const FastDiv by_mb = make_fastdiv(geo.Mb);
     if (xmode == XMODE_PERIODIC)
         hipLaunchKernelGGL((step_kernel<XMODE_PERIODIC, T>), dim3(nwg), dim3(64), lds, st, gin, gout,

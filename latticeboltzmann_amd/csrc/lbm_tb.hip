@@ -99,9 +99,39 @@
 #define LBM_TB_PADINIT 1
 #endif
 
+// 1: write-through streaming stores and line-aligned windows where the rule of TBStore allows them
+#ifndef LBM_TB_STREAM_STORE
+#define LBM_TB_STREAM_STORE 1
+#endif
+
 #include "lbm_tb_common.h"
 
 namespace lbm {
+
+// How stage T writes its rows.  The T = 1 kernel gained 2 % from `nt sc1` stores (write-through at agent
+// scope, st_stream in lbm_device.h); here that only pays when every wave-wide store covers whole
+// 128-byte lines, i.e. when the WINDOW starts on a line: fp32 storage and a margin of 16 columns (mod 32)
+// with the strips shifted by SH = 16 columns - strips then start 64 bytes into a line, which is as far as
+// they may go (a 64-byte request must not be shared by two workgroups, lbm_tb_common.h).  Same box,
+// 16384 x 16384, GLUPS (gpurun_out/r3_ab_tbalign*.log): T = 2 142.7 -> 146.8, T = 3 217.8 -> 221.6.
+// Everything else is worse than plain stores through the L2: streaming stores without the alignment
+// (T = 4 with its margin of 8: 275 -> 148-179, T = 6 320 -> 229-284), the alignment with plain stores
+// (T = 2 137.9), T = 4 with a margin of 16 and all of it (267 against 268: 4.5 % more columns computed),
+// sc1 without nt (141.3 at T = 2), non-temporal loads on top (216 at T = 3).
+template <int MARG, typename ST>
+struct TBStore {
+    static constexpr bool LINES = LBM_TB_STREAM_STORE && sizeof(ST) == 4 && MARG % 16 == 0;
+    static constexpr int SH = LINES ? MARG % 32 : LBM_TB_SH;
+};
+
+// cell c of a lane's nine populations to its place in the output row, streaming stores (st_stream)
+template <int CPL, int K = 0, typename ST, typename V>
+__device__ __forceinline__ void store_cell(ST* p, const V* out, int c) {
+    if constexpr (K < Q) {
+        st_stream<slot_of(K) * LANES * (int)sizeof(ST)>(p, LaneV<CPL>::get(out[K], c));
+        store_cell<CPL, K + 1>(p, out, c);
+    }
+}
 
 // Ring rows are addressed by ITERATION, not by row: in iteration i a stage writes its row into
 // ring row i mod depth of its level, and the next stage (two rows behind) finds rows q+1, q, q-1
@@ -124,7 +154,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     const int nchunks_ = gridDim.x / nstrips;
     const int strip = REMAP == 2 ? wg / nchunks_ : wg % nstrips;
     const int chunk = REMAP == 2 ? wg % nchunks_ : wg / nstrips;
-    const int xo = strip * C::SW - C::SH;  // first stored column (strip 0: clipped at column 0)
+    const int xo = strip * C::SW - TBStore<MARG, ST>::SH;  // first stored column (strip 0: clipped at column 0)
     const int y0 = row0 + chunk * Ry;
     const int y1 = min(y0 + Ry, row0 + nrows);
     const int N = geo.N, M = geo.M, G = geo.G;
@@ -447,9 +477,13 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
 #pragma unroll
                             for (int c = 0; c < CPL; c++) {
                                 if (stored[c]) {
+                                    if constexpr (TBStore<MARG, ST>::LINES) {
+                                        store_cell<CPL>(orow + off0[c], out, c);
+                                    } else {
 #pragma unroll
-                                    for (int k = 0; k < Q; k++)
-                                        LBM_TB_STORE(orow + off0[c] + slot_of(k) * LANES, L::get(out[k], c));
+                                        for (int k = 0; k < Q; k++)
+                                            LBM_TB_STORE(orow + off0[c] + slot_of(k) * LANES, L::get(out[k], c));
+                                    }
                                 }
                             }
                         }
@@ -515,7 +549,7 @@ template <int XMODE, int T, int NB, int CPL, int MARG, typename ST>
 static void launch_tb_t(const ST* gin, ST* gout, const uint64_t* mask, const Geom& geo, int row0,
                         int nrows, int Ry, hipStream_t st) {
     using C = TB<T, NB, CPL, MARG>;
-    const int nstrips = (geo.M + C::SH + C::SW - 1) / C::SW;
+    const int nstrips = (geo.M + TBStore<MARG, ST>::SH + C::SW - 1) / C::SW;
     if (Ry <= 0) {
         // per process and instantiation: all devices of a node are the same part (a benign race:
         // concurrent first calls compute the same value)
