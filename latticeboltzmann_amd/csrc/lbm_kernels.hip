@@ -15,7 +15,7 @@ namespace lbm {
 // Replaces fcs<> (lb_cuda_kernel.cu:209-370).  One wavefront per (row, xb) tile of 64 cells:
 // 9 wave-wide loads (3 x 768 contiguous bytes from rows y-1, y, y+1; the dx = +-1 ones shifted by
 // one lane, crossing into the neighbouring chunk for one lane), ~110 VALU, 9 aligned 256-byte
-// stores that fill one contiguous 2304-byte chunk.  No LDS, no barrier: nothing is reused.
+// write-through stores (`nt sc1`, st_stream) that fill one contiguous 2304-byte chunk.  No LDS, no barrier: nothing is reused.
 // Algorithmic HBM bytes per cell-update: 36 read + 36 written (latticeboltzmann.py:176).
 // ---------------------------------------------------------------------------------------------
 // a lane's nine populations into its chunk (wave-uniform address), streaming stores (st_stream, lbm_device.h)
