@@ -110,18 +110,26 @@ namespace lbm {
 
 // How stage T writes its rows.  The T = 1 kernel gained 2 % from `nt sc1` stores (write-through at agent
 // scope, st_stream in lbm_device.h); here that only pays when every wave-wide store covers whole
-// 128-byte lines, i.e. when the WINDOW starts on a line: fp32 storage and a margin of 16 columns (mod 32)
-// with the strips shifted by SH = 16 columns - strips then start 64 bytes into a line, which is as far as
-// they may go (a 64-byte request must not be shared by two workgroups, lbm_tb_common.h).  Same box,
-// 16384 x 16384, GLUPS (gpurun_out/r3_ab_tbalign*.log): T = 2 142.7 -> 146.8, T = 3 217.8 -> 221.6.
-// Everything else is worse than plain stores through the L2: streaming stores without the alignment
-// (T = 4 with its margin of 8: 275 -> 148-179, T = 6 320 -> 229-284), the alignment with plain stores
-// (T = 2 137.9), T = 4 with a margin of 16 and all of it (267 against 268: 4.5 % more columns computed),
-// sc1 without nt (141.3 at T = 2), non-temporal loads on top (216 at T = 3).
+// 128-byte lines - written through, partial lines are poison (T = 4: 275 -> 148 GLUPS).  The windows
+// start MARG columns left of their strips, 32 or 64 bytes into a line, so with fp32 storage stage T
+// works on columns SHIFTED by dsh in [-MARG, MARG] against the other stages (it reads the rings of level
+// T-1 at any column it likes; the columns it thereby leaves out at one window edge and adds beyond the
+// other are outside the strip): dsh = the shift that puts its wave-wide stores on line boundaries.
+// Strips start on multiples of 16 columns, so this is +-8 or 0 / 16; only the line at a strip boundary
+// that is not a line boundary (SW is an odd multiple of 16 columns at T >= 4: every second boundary)
+// is still written in two halves.  fp16 storage (a line is 64 columns) keeps plain stores.
+// Same box, 16384 x 16384, GLUPS: see profiles/r03_tb_hbm.md section 3d.
 template <int MARG, typename ST>
 struct TBStore {
-    static constexpr bool LINES = LBM_TB_STREAM_STORE && sizeof(ST) == 4 && MARG % 16 == 0;
-    static constexpr int SH = LINES ? MARG % 32 : LBM_TB_SH;
+    static constexpr bool LINES = LBM_TB_STREAM_STORE && sizeof(ST) == 4;
+    static constexpr int SH = LBM_TB_SH;
+    // first stored column xo -> shift of stage T's columns
+    static __device__ __forceinline__ int shift(int xo) {
+        if (!LINES) return 0;
+        int r = (MARG - xo) & 31;
+        if (r > MARG) r -= 32;
+        return r >= -MARG ? r : 0;  // (xo not a multiple of 16: LBM_TB_SH experiments)
+    }
 };
 
 // cell c of a lane's nine populations to its place in the output row, streaming stores (st_stream)
@@ -175,7 +183,8 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     constexpr int WPS = NB / CPL;  // waves per stage
     const int s = wave / WPS + 1;
     const int j = wave % WPS;
-    const int cx = C::PADC + j * (64 * CPL) + lane;  // ring-row index of cell 0; cell c is 64*c further
+    const int dsh = s == T ? TBStore<MARG, ST>::shift(xo) : 0;  // stage T: stores on line boundaries (TBStore)
+    const int cx = C::PADC + j * (64 * CPL) + lane + dsh;  // ring-row index of cell 0; cell c is 64*c further
     int off0[CPL];
     unsigned bo0[CPL], bom[CPL], bop[CPL];  // byte offsets of the own / dx = -1 / dx = +1 source column in a row
     unsigned mwoff[CPL];                    // this cell's 32-bit mask word (byte offset in a mask row)
@@ -185,14 +194,14 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     bool any_xedge = false;
 #pragma unroll
     for (int c = 0; c < CPL; c++) {
-        const int x = xo - MARG + j * (64 * CPL) + c * 64 + lane;  // logical column
+        const int x = xo - MARG + j * (64 * CPL) + c * 64 + lane + dsh;  // logical column
         int xn;                                                       // storage column
         if (XMODE == XMODE_PERIODIC) { xn = x % M; if (xn < 0) xn += M; }
         else xn = min(max(x, 0), M - 1);  // outside the domain: a valid address, never stored
         stored[c] = x >= xo && x >= 0 && x < xo + C::SW && x < M;
         // level s is only right s-1 columns inside the window (see the header): the columns
         // beyond compute on stale ring contents and nobody reads what they produce
-        const int wc = j * (64 * CPL) + c * 64 + lane;
+        const int wc = j * (64 * CPL) + c * 64 + lane + dsh;
         care[c] = wc >= s - 1 && wc < C::W - (s - 1);
         caremask[c] = ballot(care[c]);
         // x edge rule (reference mode only): source of dx = -1 / +1 outside the domain
@@ -519,7 +528,7 @@ __global__ __launch_bounds__((TB<T, NB, CPL, MARG>::NW * 64)) void step_tb_kerne
     // A wave whose columns all lie beyond what the strip needs (the last strip of a row is
     // usually narrower than the window) only keeps the barriers company: no loads, no arithmetic.
     const int need_hi = min(xo + C::SW, M) + MARG;  // logical columns at or beyond: nobody's input
-    if (!LBM_TB_NODEAD && xo - MARG + j * (64 * CPL) >= need_hi) {
+    if (!LBM_TB_NODEAD && xo - MARG + j * (64 * CPL) + dsh >= need_hi) {
         for (int i = 0; i < nit; i++) __syncthreads();
         return;
     }

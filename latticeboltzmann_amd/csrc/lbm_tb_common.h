@@ -48,10 +48,11 @@ struct TB {
     // x-shift serves all nine slots in all four phases, and the row loop has no LDS address
     // arithmetic at all.  The window-edge lanes (whose results are nobody's input, see `care`) read
     // their missing neighbour column from the adjacent slot row instead of a pad column: ordinary
-    // populations; FRONT bytes in front of level 1 give its first slot row a column -1.
+    // populations; FRONT bytes in front of level 1 give its first slot row the columns -1 ... -MARG-1
+    // (stage T may work on columns shifted by up to MARG, TBStore in lbm_tb.hip).
     static constexpr int PADC = LBM_TB_PADC;     // pad columns either side of a slot row (0; 1 = the older layout)
     static constexpr int RW = W + 2 * PADC;      // floats per slot row
-    static constexpr int FRONT = 16;
+    static constexpr int FRONT = 4 * MARG + 16;
     static constexpr int A_ROW = 3 * RW * 4;     // bytes per ring row of slots 0-2
     static constexpr int B_ROW = 6 * RW * 4;     // bytes per ring row of slots 3-8
     static constexpr int B_OFF = DA * A_ROW;
