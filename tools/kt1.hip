@@ -19,6 +19,14 @@
 using namespace lbm;
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+// scalar streaming store: `nt` as hipcc's builtin gives it, or (-DKT1_ST_POLICY='"nt sc1"') the policy
+// the product kernels use since the end of round 3 (profiles/r03_t1_layout.md section 0)
+#ifdef KT1_ST_POLICY
+#define NTST(v, p) asm volatile("global_store_dword %0, %1, off " KT1_ST_POLICY :: "v"(p), "v"((float)(v)) : "memory")
+#else
+#define NTST(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
 struct Lay {
     int N, Mb, P;        // rows, blocks per row, blocks per panel (P == Mb: plain row-major)
     long long panelStride;  // elements per panel = N * S * CHUNK
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(64) void kt1(const float* __restrict__ gin, float* 
         collide_to(v, false, 0ull, omega_of(geo), [&](const float* out) {
             float* o = gout + (long long)pn * L.panelStride + ((long long)y * L.S + xi) * CHUNK + lane;
 #pragma unroll
-            for (int k = 0; k < Q; k++) __builtin_nontemporal_store(out[k], o + slot_of(k) * LANES);
+            for (int k = 0; k < Q; k++) NTST(out[k], o + slot_of(k) * LANES);
         });
         return;
     }
@@ -100,12 +108,12 @@ __global__ __launch_bounds__(64) void kt1(const float* __restrict__ gin, float* 
         float* o = gout + o0[1];
         if (KIND == K_WR1) {
 #pragma unroll
-            for (int k = 0; k < Q; k++) __builtin_nontemporal_store((float)(tile + k), o + 64 * k + lane);
+            for (int k = 0; k < Q; k++) NTST((float)(tile + k), o + 64 * k + lane);
         } else if (KIND == K_WR4) {
             const v4 v = {(float)tile, 1.0f, 2.0f, (float)lane};
             __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o) + lane);
             __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o) + 64 + lane);
-            __builtin_nontemporal_store((float)tile, o + 512 + lane);
+            NTST((float)tile, o + 512 + lane);
         } else {
             __shared__ float t[512];
             const float* p = gin + o0[1] + lane;
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(64) void kt1(const float* __restrict__ gin, float* 
             const v4 w0 = reinterpret_cast<const v4*>(t)[lane], w1 = reinterpret_cast<const v4*>(t)[64 + lane];
             __builtin_nontemporal_store(w0, reinterpret_cast<v4*>(o) + lane);
             __builtin_nontemporal_store(w1, reinterpret_cast<v4*>(o) + 64 + lane);
-            __builtin_nontemporal_store(a[8], o + 512 + lane);
+            NTST(a[8], o + 512 + lane);
         }
         return;
     }
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(64) void kt1(const float* __restrict__ gin, float* 
         for (int k = 0; k < Q; k++) a[k] = __builtin_nontemporal_load(p + 64 * k) + 1.0f;  // (a changed value: `*p = *p` would be deleted)
         float* o = (INPLACE ? const_cast<float*>(gin) : gout) + o0[1] + lane;
 #pragma unroll
-        for (int k = 0; k < Q; k++) __builtin_nontemporal_store(a[k], o + 64 * k);
+        for (int k = 0; k < Q; k++) NTST(a[k], o + 64 * k);
         return;
     }
     if (KIND == K_COPY3W || KIND == K_COPY3WS) {
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(64) void kt1(const float* __restrict__ gin, float* 
 #pragma unroll
         for (int k = 0; k < Q; k++) {
             const int dy = dy_of(k), sl = slot_of(k) * LANES;
-            __builtin_nontemporal_store(a[k], gout + o0[1 - dy] + lane + sl);  // to row y + dy
+            NTST(a[k], gout + o0[1 - dy] + lane + sl);  // to row y + dy
         }
         return;
     }
@@ -164,17 +172,17 @@ __global__ __launch_bounds__(64) void kt1(const float* __restrict__ gin, float* 
         collide_to(a, false, 0ull, omega_of(geo), [&](const float* out) {
             float* o = gout + o0[1] + lane;
 #pragma unroll
-            for (int k = 0; k < Q; k++) __builtin_nontemporal_store(out[k], o + slot_of(k) * LANES);
+            for (int k = 0; k < Q; k++) NTST(out[k], o + slot_of(k) * LANES);
         });
         return;
     }
     if (INPLACE) {
 #pragma unroll
-        for (int k = 0; k < Q; k++) __builtin_nontemporal_store(a[k] + 1.0f, const_cast<float*>(src[k]));
+        for (int k = 0; k < Q; k++) NTST(a[k] + 1.0f, const_cast<float*>(src[k]));
     } else {
         float* o = gout + o0[1] + lane;
 #pragma unroll
-        for (int k = 0; k < Q; k++) __builtin_nontemporal_store(a[k], o + slot_of(k) * LANES);
+        for (int k = 0; k < Q; k++) NTST(a[k], o + slot_of(k) * LANES);
     }
 }
 
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(64) void kt1r(const float* __restrict__ gin, float*
         collide_to(v[r], false, 0ull, omega_of(geo), [&](const float* out) {
             float* o = gout + ((long long)(y0 + r) * L.S + xi) * CHUNK + lane;
 #pragma unroll
-            for (int k = 0; k < Q; k++) __builtin_nontemporal_store(out[k], o + slot_of(k) * LANES);
+            for (int k = 0; k < Q; k++) NTST(out[k], o + slot_of(k) * LANES);
         });
     }
 }
