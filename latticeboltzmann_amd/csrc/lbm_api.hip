@@ -436,6 +436,10 @@ static int advance(lbm_solver* s, long long total, int max_depth) {
         // costs more than half a depth-6 one)
         const long long nl = (total + max_depth - 1) / max_depth;
         int t = (int)((total + nl - 1) / nl);
+        // ... except that depth 5 is the slow one (ten waves on four SIMDs: per update slower than depth 4,
+        // DESIGN section 5): when more launches follow anyway, 10 goes as 6 + 4 and 15 as 6 + 6 + 3, not
+        // as 5 + 5 (+ 5).  The number of launches stays the same.
+        if (t == 5 && total > 5 && max_depth >= 6) t = 6;
         if (seam) t = std::min(t, s->ghost_valid);
         if (s->xmode == XMODE_CUDA) t = 1;
         if (g.M < 8 || g.N < 16) t = 1;  // tiny domains: rows wrap at most once in the strip pipeline
@@ -455,8 +459,8 @@ static int advance(lbm_solver* s, long long total, int max_depth) {
     return LBM_OK;
 }
 
-// One outer iteration = inner_timesteps updates, split into ceil(T / depth_cap) balanced launches
-// (e.g. T = 6 -> 3 + 3).
+// One outer iteration = inner_timesteps updates, in ceil(T / depth_cap) balanced launches (advance();
+// e.g. T = 7 at cap 6 -> 4 + 3).
 static int outer_iteration(lbm_solver* s) {
     int rem = s->T;
     if (!s->pulled) {
@@ -465,14 +469,7 @@ static int outer_iteration(lbm_solver* s) {
         rem--;
     }
     if (rem <= 0) return LBM_OK;
-    const int cap = depth_cap(s);
-    const int nl = (rem + cap - 1) / cap;
-    for (int i = 0; i < nl; i++) {
-        const int t = rem / nl + (i < rem % nl ? 1 : 0);
-        int rc = advance(s, t, t);
-        if (rc) return rc;
-    }
-    return LBM_OK;
+    return advance(s, rem, depth_cap(s));
 }
 
 int lbm_fused_collide_stream(lbm_solver* s, int n_outer) {

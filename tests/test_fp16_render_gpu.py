@@ -144,10 +144,13 @@ def _launch_depths(T, cap, n_outer, tiny):
         first = False
         if rem <= 0:
             continue
-        nl = -(-rem // cap)
-        for i in range(nl):
-            d = rem // nl + (1 if i < rem % nl else 0)
+        while rem > 0:
+            nl = -(-rem // cap)
+            d = -(-rem // nl)
+            if d == 5 and rem > 5 and cap >= 6:
+                d = 6  # depth 5 is the slow one: 10 = 6 + 4
             depths += [1] * d if tiny else [d]
+            rem -= d
     return depths
 
 

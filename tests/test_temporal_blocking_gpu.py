@@ -45,10 +45,11 @@ def test_tb_small(boundary, T, shape, tb_rows):
     _run_case(shape[0], shape[1], T, boundary, tb_rows, tb_max=6)  # one launch of depth T
 
 
-@pytest.mark.parametrize("T,tb_max", [(5, 4), (6, 4), (7, 6), (9, 6), (5, 2), (3, 1)])
+@pytest.mark.parametrize("T,tb_max", [(5, 4), (6, 4), (7, 6), (9, 6), (10, 6), (15, 6), (5, 2), (3, 1)])
 def test_tb_split_depths(T, tb_max):
     """inner_timesteps beyond the deepest launch in use are split into balanced launches
-    (cap 4: 5=3+2, 6=3+3; cap 6: 7=4+3, 9=5+4; cap 2: 5=2+2+1; cap 1: the T=1 kernel only)."""
+    (cap 4: 5=3+2, 6=3+3; cap 6: 7=4+3, 9=6+3, 10=6+4, 15=6+6+3 - depth 5 is avoided when more launches follow;
+    cap 2: 5=2+2+1; cap 1: the T=1 kernel only)."""
     _run_case(48, 320, T, "reference", 16, n_outer=2, tb_max=tb_max)
     _run_case(48, 320, T, "periodic", 16, n_outer=2, tb_max=tb_max)
 
