@@ -31,14 +31,14 @@ struct TB {
     static constexpr int DA = 2;                 // ring depth of the dy = -1 slots
     static constexpr int W = NB * 64;            // window width (columns computed per stage)
     static constexpr int SW = W - 2 * MARG;      // strip width (columns stored)
-    // Strip s stores columns [s*SW - SH, (s+1)*SW - SH) (clipped to the domain); SH is chosen per storage
-    // type in lbm_tb.hip (TBStore).  Strips must start on multiples of 16 fp32 columns = 64 bytes, so that
+    // Strip s stores columns [s*SW - SH, (s+1)*SW - SH) (clipped to the domain); SH = LBM_TB_SH, a
+    // development knob that stays 0 (TBStore in lbm_tb.hip).  Strips must start on multiples of 16 fp32 columns = 64 bytes, so that
     // no 64-byte write request is shared by two workgroups (two XCDs): with MARG = 8 the WINDOW then
     // starts 32 bytes into a request and every wave-wide store is five L1->L2 write requests instead of
     // four (TCP_TCC_WRITE_REQ 1.22x the ideal at T = 4), but those halves meet in one L2 and cost nothing
     // - shifting the strips so that the windows are aligned instead (SH = 8) costs 17 % at T = 4 (275 ->
     // 227 GLUPS), any other shift 7-8 %, 2-6 % at T = 2 / 3 (profiles/r03_tb_hbm.md, round 3).
-    // LBM_TB_SH: development knob, the shift where TBStore has no rule of its own.
+    // (What does get shifted, since the end of round 3, is the set of columns the LAST stage works on.)
 #ifndef LBM_TB_SH
 #define LBM_TB_SH 0
 #endif
